@@ -1,0 +1,217 @@
+/*
+ * rtx950.h — C ABI of the MI355X-native ray-cast renderer (drop-in boundary).
+ *
+ * The reference (ElrohirGT/Raytracing, a pure-Rust crate) has no FFI of its own; its de-facto
+ * operator boundary is
+ *
+ *     pub fn render(framebuffer: &mut Framebuffer, data: &Model)      reference src/render.rs:234
+ *     pub fn init_render(framebuffer: &mut Framebuffer, data: &Model) reference src/render.rs:13
+ *
+ * Every entry point below is what a Rust `extern "C"` block for that path would bind (the
+ * binding itself is shown in INTEGRATION.md).  Plain pointers and sizes only; no C++ or torch
+ * types cross this boundary.  All structs are plain-old-data with natural alignment and are
+ * layout-compatible with `#[repr(C)]` Rust structs of the same field order.
+ *
+ * Conventions
+ *   - every function returns an `int` status: 0 = RT_OK, negative = error (see rt_status);
+ *     nothing throws or aborts across the boundary; `rt_last_error` gives the message.
+ *   - colours are packed 0x00RRGGBB, exactly `From<Color> for u32` (reference src/color.rs:76-79).
+ *   - a context is used by one host thread at a time; distinct contexts are independent
+ *     (reference `render` needs `&mut Framebuffer`, so it is not re-entrant either).
+ */
+#ifndef RTX950_H
+#define RTX950_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX950_ABI_VERSION 1u
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,   /* null pointer, zero size, bad band, bad index in a record   */
+    RT_ERR_NO_DEVICE = -2,     /* HIP runtime reports no usable GPU / bad device ordinal     */
+    RT_ERR_HIP = -3,           /* a HIP call failed; message carries hipGetErrorString       */
+    RT_ERR_NO_SCENE = -4,      /* rt_render* called before rt_scene_upload                   */
+    RT_ERR_UNSUPPORTED = -5,   /* e.g. max_depth > 3, more lights than RT_MAX_LIGHTS         */
+    RT_ERR_LIMIT = -6          /* a fixed-capacity entry point was given too large an input  */
+} rt_status;
+
+/* reference src/render.rs:83 — `if depth > 3 { return sky }` */
+#define RT_MAX_DEPTH 3u
+/* capacity of the per-frame light table (reference uses 2: src/render.rs:241-243) */
+#define RT_MAX_LIGHTS 16u
+/* `texture: None` (reference src/material.rs:6, RUBBER at :114-122) */
+#define RT_TEXTURE_NONE (-1)
+/* value stored in hit-index planes where the depth-0 ray hit nothing */
+#define RT_NO_HIT 0xFFFFFFFFu
+
+typedef struct rt_vec3 { float x, y, z; } rt_vec3;
+
+/* reference src/cube.rs:13-19 `Cube { id, center, size, material, bounds }`; bounds are derived
+ * inside rt_scene_upload exactly as `Cube::compute_bounds` (src/cube.rs:51-66): center -/+ size/2.
+ * `material` indexes the rt_material table passed to rt_scene_upload. */
+typedef struct rt_cube {
+    uint32_t id;
+    rt_vec3  center;
+    float    size;
+    uint32_t material;
+} rt_cube;
+
+/* reference src/sphere.rs:10-15 `Sphere { id, center, radius, material }` */
+typedef struct rt_sphere {
+    uint32_t id;
+    rt_vec3  center;
+    float    radius;
+    uint32_t material;
+} rt_sphere;
+
+/* reference src/material.rs:4-18 `Material`.  `texture` is an index into the atlas array given
+ * to rt_scene_upload (the order of `enum Textures`, src/texture.rs:35-45) or RT_TEXTURE_NONE. */
+typedef struct rt_material {
+    uint32_t diffuse_0rgb;
+    int32_t  texture;
+    float    specular;
+    float    albedo0;
+    float    albedo1;
+    float    reflectivity;
+    float    transparency;
+    float    refractive_index;
+} rt_material;
+
+/* reference src/light.rs:5-9 `Light { position, color, intensity }` */
+typedef struct rt_light {
+    rt_vec3  position;
+    uint32_t color_0rgb;
+    float    intensity;
+} rt_light;
+
+/* reference src/camera.rs:5-17 (eye, center, up); `has_changed` is host-loop state, not render input */
+typedef struct rt_camera {
+    rt_vec3 eye;
+    rt_vec3 center;
+    rt_vec3 up;
+} rt_camera;
+
+/* Everything `render` reads from `&Model` (reference src/lib.rs:42-52) that is per-frame, plus the
+ * framebuffer geometry (src/framebuffer.rs:6-13) and the scanline band this call renders.
+ *   lights      — `data.lights` followed by `data.top_light`, the order render.rs:241-243 builds
+ *   ambient     — `data.ambient_light`, used for the cube pass (render.rs:299); the sphere pass
+ *                 uses the literal 1.0 (render.rs:269) inside the library
+ *   y0,y1       — rows [y0,y1) of the full width x height frame are rendered; 0,height = whole frame
+ *   max_depth   — reference constant 3 (render.rs:83); 0..3 accepted
+ */
+typedef struct rt_frame {
+    rt_camera       camera;
+    uint32_t        width;
+    uint32_t        height;
+    uint32_t        y0;
+    uint32_t        y1;
+    const rt_light* lights;
+    uint32_t        n_lights;
+    float           ambient_light;
+    uint32_t        sky_0rgb;
+    uint32_t        max_depth;
+} rt_frame;
+
+/* Optional per-pixel debug planes for the bit-exact parity check (no reference analogue: the
+ * reference keeps these values only transiently, src/render.rs:87-101).  Any pointer may be NULL.
+ * Each plane has (y1-y0)*width u32 entries, row-major, band-relative.
+ *   hit_cube   — array index of the nearest cube hit by the depth-0 ray of the cube pass, or RT_NO_HIT
+ *   hit_sphere — same for the sphere pass
+ *   tree_hash  — FNV-1a style hash over every object index the pixel's whole ray tree selected
+ *                (nearest hit and shadow blocker per light, every depth, both passes)
+ */
+typedef struct rt_debug_planes {
+    uint32_t* hit_cube;
+    uint32_t* hit_sphere;
+    uint32_t* tree_hash;
+} rt_debug_planes;
+
+/* Ray/test counters of one rt_render* call (summed over the band).  "uniq" counts what the GPU
+ * executes (secondary rays traced once per hit); the reference re-casts them once per light
+ * (src/render.rs:154-193 sits inside the fold at :104-106). */
+typedef struct rt_counters {
+    uint64_t nearest_rays;    /* object-list traversals for a nearest hit (render.rs:87-101) */
+    uint64_t shadow_rays;     /* object-list traversals for a shadow query (render.rs:44-70) */
+    uint64_t cube_tests;      /* executed Cube::ray_intersect calls (early exit honoured)    */
+    uint64_t sphere_tests;    /* executed Sphere::ray_intersect calls                        */
+    uint64_t shaded_hits;     /* nearest-hit queries that found an object                    */
+} rt_counters;
+
+typedef struct rt_ctx rt_ctx;
+
+/* ABI / build identification.  No reference counterpart (library housekeeping). */
+uint32_t rt_abi_version(void);
+
+/* Create / destroy one context bound to HIP device `device` (one per GPU; owns a stream, the
+ * device-resident scene, the device framebuffer and a pinned read-back buffer).
+ * Replaces: construction of `Framebuffer::new` (reference src/framebuffer.rs:44-58) + `Model`
+ * (src/main.rs:249-259) as far as device state is concerned. */
+int rt_ctx_create(int device, rt_ctx** out_ctx);
+int rt_ctx_destroy(rt_ctx* ctx);
+
+/* Message of the last failing call on this context (or on the calling thread if ctx is NULL).
+ * Replaces the reference's `unwrap`/`expect` panics (src/texture.rs:142, src/main.rs:41,141). */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Upload the static part of `Model`: cubes, spheres (src/lib.rs:43-44), the material table
+ * (src/material.rs:34-122) and the texture atlases (src/texture.rs:22-32, loaded by
+ * `Texture::new`, :141-169, as row-major RGB8: 3 bytes per texel, `idx = y*width + x`).
+ * Host arrays are copied; the caller keeps ownership.  n_cubes / n_spheres may be 0.
+ *   atlas_rgb8 — n_textures consecutive images of tex_w*tex_h*3 bytes
+ *   sprite     — `sprite_size` (16 in the reference, src/texture.rs:59-67)
+ */
+int rt_scene_upload(rt_ctx* ctx,
+                    const rt_cube* cubes, size_t n_cubes,
+                    const rt_sphere* spheres, size_t n_spheres,
+                    const rt_material* materials, size_t n_materials,
+                    const uint8_t* atlas_rgb8, size_t n_textures,
+                    uint32_t tex_w, uint32_t tex_h, uint32_t sprite);
+
+/* render(framebuffer, data) — reference src/render.rs:234-324.  Synchronous, like the reference.
+ * Renders rows [y0,y1) and copies them to host memory `out_0rgb` ((y1-y0)*width u32, 0x00RRGGBB,
+ * `framebuffer.buffer` layout, src/framebuffer.rs:15,105).  Reproduces the reference's unpainted
+ * pixel i == width (src/render.rs:316-322 -> XTooLarge, src/framebuffer.rs:101-102), which keeps
+ * the clear colour 0x000000 (src/framebuffer.rs:45,63-65).
+ * `dbg_host` (nullable) receives the debug planes in host memory. */
+int rt_render(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_0rgb,
+              const rt_debug_planes* dbg_host);
+
+/* Same computation, but the output (and debug planes, if any) are DEVICE pointers on the
+ * context's GPU and nothing is copied to the host; the call returns after the kernel has been
+ * enqueued on the context's stream (rt_sync waits).  This is what a multi-GPU host uses to render
+ * its band straight into a buffer it then gathers over xGMI, and what bench.py times.
+ * Replaces the same reference function (src/render.rs:234). */
+int rt_render_device(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out_0rgb,
+                     const rt_debug_planes* dbg_device);
+
+/* Wait for all work enqueued on the context's stream.  No reference counterpart (the reference
+ * is synchronous). */
+int rt_sync(rt_ctx* ctx);
+
+/* Run the counting variant of the render kernel on the band (no image output) and return the
+ * ray / test counters.  No reference counterpart; used for the Mrays/s metric and checked
+ * against the oracle's counters in tests. */
+int rt_count_rays(rt_ctx* ctx, const rt_frame* frame, rt_counters* out);
+
+/* Average device time, in milliseconds, of the render kernel launches issued since the last call
+ * (measured with HIP events on the context's stream), and their number.  No reference counterpart
+ * (the reference shows fps in its window title, src/main.rs:122-131). */
+int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches);
+
+/* Toggle HIP-event timing of rt_render_device launches (off by default). */
+int rt_enable_timing(rt_ctx* ctx, int enable);
+
+/* Raw HIP stream of the context as an opaque pointer (hipStream_t), for hosts that order their
+ * own work (e.g. an RCCL gather) after the render.  No reference counterpart. */
+int rt_get_stream(rt_ctx* ctx, void** out_hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX950_H */

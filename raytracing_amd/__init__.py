@@ -1,0 +1,13 @@
+"""raytracing_amd — MI355X-native renderer for the ElrohirGT/Raytracing per-pixel ray-cast path.
+
+Layout: csrc/ (HIP kernels + the C-ABI of include/rtx950.h), host/ (C++ mirror of the reference's
+scene/API surface), api.py (Python face used by tests and bench).  Importing this package does not
+load the shared libraries; the first call that needs them does, and fails loudly if they are absent.
+"""
+from . import _ffi  # noqa: F401
+from .api import (Context, RtError, Scene, bmp_encode, default_scene, make_scene, render, rotate_cam,  # noqa: F401
+                  synthetic_scene, DAY_COLOR, NIGHT_COLOR, DEFAULT_MATERIAL_SEED, SYNTHETIC_SEED)
+from ._ffi import (Camera, Counters, Cube, DebugPlanes, Frame, Light, Material, Sphere, Vec3,  # noqa: F401
+                   RT_MAX_DEPTH, RT_MAX_LIGHTS, RT_NO_HIT, RT_TEXTURE_NONE)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

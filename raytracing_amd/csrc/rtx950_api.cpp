@@ -1,0 +1,443 @@
+// rtx950_api.cpp — the extern "C" boundary declared in include/rtx950.h.
+//
+// Host-side work per call is what the reference does outside its pixel loops: validate, derive
+// cube bounds (reference src/cube.rs:51-66), hoist the camera basis (src/camera.rs:34-36, a pure
+// function of the camera that the reference recomputes per pixel), assemble kernel parameters,
+// launch.  There is no CPU rendering path here: if HIP or the GPU is missing every call fails
+// with RT_ERR_NO_DEVICE / RT_ERR_HIP.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rtx950.h"
+#include "rtx950_device.h"
+
+using namespace rtx950;
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    bool has_scene = false;
+    CubeRec* d_cubes = nullptr;
+    uint32_t* d_cube_mat = nullptr;
+    SphereRec* d_spheres = nullptr;
+    SphereMeta* d_sphere_meta = nullptr;
+    MatRec* d_mats = nullptr;
+    uint32_t* d_atlas = nullptr;
+    Params base{};
+    // framebuffer + debug planes owned by the context (used by rt_render)
+    uint32_t* d_fb = nullptr;
+    size_t fb_capacity = 0;  // in pixels
+    uint32_t* d_dbg[3] = {nullptr, nullptr, nullptr};
+    size_t dbg_capacity[3] = {0, 0, 0};
+    unsigned long long* d_counters = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded pairs since last query
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+};
+
+namespace {
+
+thread_local std::string g_tls_err;
+
+int fail(rt_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    g_tls_err = msg;
+    return code;
+}
+
+int fail_hip(rt_ctx* ctx, hipError_t e, const char* what)
+{
+    return fail(ctx, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, expr)                                   \
+    do {                                                     \
+        hipError_t e__ = (expr);                             \
+        if (e__ != hipSuccess) return fail_hip(ctx, e__, #expr); \
+    } while (0)
+
+struct H3 {
+    float x, y, z;
+};
+// nalgebra-glm semantics (see oracle/rt_oracle.c): dot = (a0*b0 + a1*b1) + a2*b2, normalize divides
+H3 h_sub(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+float h_dot(H3 a, H3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+H3 h_cross(H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+H3 h_normalize(H3 a)
+{
+    float n = std::sqrt(h_dot(a, a));
+    return H3{a.x / n, a.y / n, a.z / n};
+}
+
+void free_scene(rt_ctx* c)
+{
+    (void)hipFree(c->d_cubes);
+    (void)hipFree(c->d_cube_mat);
+    (void)hipFree(c->d_spheres);
+    (void)hipFree(c->d_sphere_meta);
+    (void)hipFree(c->d_mats);
+    (void)hipFree(c->d_atlas);
+    c->d_cubes = nullptr;
+    c->d_cube_mat = nullptr;
+    c->d_spheres = nullptr;
+    c->d_sphere_meta = nullptr;
+    c->d_mats = nullptr;
+    c->d_atlas = nullptr;
+    c->has_scene = false;
+}
+
+template <typename T>
+int upload(rt_ctx* ctx, T** dptr, const std::vector<T>& host)
+{
+    // one spare element so zero-length arrays still have a valid address
+    size_t bytes = (host.size() + 1) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc((void**)dptr, bytes));
+    HIP_TRY(ctx, hipMemset(*dptr, 0, bytes));
+    if (!host.empty()) HIP_TRY(ctx, hipMemcpy(*dptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int check_frame(rt_ctx* ctx, const rt_frame* f)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
+    if (!f) return fail(ctx, RT_ERR_INVALID_ARG, "frame is null");
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called on this context");
+    if (f->width == 0 || f->height == 0) return fail(ctx, RT_ERR_INVALID_ARG, "frame width/height must be non-zero");
+    if (f->width > 65536u || f->height > 65536u) return fail(ctx, RT_ERR_UNSUPPORTED, "frame larger than 65536 in a dimension");
+    if (f->y0 >= f->y1 || f->y1 > f->height) return fail(ctx, RT_ERR_INVALID_ARG, "band must satisfy y0 < y1 <= height");
+    if (f->max_depth > RT_MAX_DEPTH) return fail(ctx, RT_ERR_UNSUPPORTED, "max_depth > 3 is not supported (reference constant is 3)");
+    if (f->n_lights > RT_MAX_LIGHTS) return fail(ctx, RT_ERR_UNSUPPORTED, "more than RT_MAX_LIGHTS lights");
+    if (f->n_lights > 0 && !f->lights) return fail(ctx, RT_ERR_INVALID_ARG, "lights is null but n_lights > 0");
+    return RT_OK;
+}
+
+void fill_frame(const rt_ctx* ctx, const rt_frame* f, Params& p)
+{
+    p = ctx->base;
+    const H3 eye{f->camera.eye.x, f->camera.eye.y, f->camera.eye.z};
+    const H3 center{f->camera.center.x, f->camera.center.y, f->camera.center.z};
+    const H3 upv{f->camera.up.x, f->camera.up.y, f->camera.up.z};
+    const H3 forward = h_normalize(h_sub(center, eye));     // camera.rs:34
+    const H3 right = h_normalize(h_cross(forward, upv));    // camera.rs:35
+    const H3 up = h_normalize(h_cross(right, forward));     // camera.rs:36
+    p.eye[0] = eye.x; p.eye[1] = eye.y; p.eye[2] = eye.z;
+    p.right[0] = right.x; p.right[1] = right.y; p.right[2] = right.z;
+    p.up[0] = up.x; p.up[1] = up.y; p.up[2] = up.z;
+    p.fwd[0] = forward.x; p.fwd[1] = forward.y; p.fwd[2] = forward.z;
+    p.width = f->width;
+    p.height = f->height;
+    p.y0 = f->y0;
+    p.y1 = f->y1;
+    p.ambient = f->ambient_light;
+    p.sky = f->sky_0rgb & 0x00FFFFFFu;
+    p.max_depth = f->max_depth;
+    p.n_lights = f->n_lights;
+    for (uint32_t i = 0; i < f->n_lights; ++i) {
+        p.lights[i].px = f->lights[i].position.x;
+        p.lights[i].py = f->lights[i].position.y;
+        p.lights[i].pz = f->lights[i].position.z;
+        p.lights[i].color_0rgb = f->lights[i].color_0rgb & 0x00FFFFFFu;
+        p.lights[i].intensity = f->lights[i].intensity;
+    }
+    p.out = nullptr;
+    p.hit_cube = nullptr;
+    p.hit_sphere = nullptr;
+    p.tree_hash = nullptr;
+    p.counters = nullptr;
+}
+
+int ensure(rt_ctx* ctx, uint32_t** buf, size_t* cap, size_t need)
+{
+    if (*cap >= need) return RT_OK;
+    if (*buf) HIP_TRY(ctx, hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)buf, need * sizeof(uint32_t)));
+    *cap = need;
+    return RT_OK;
+}
+
+int launch_timed(rt_ctx* ctx, const Params& p, int variant)
+{
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (ctx->timing) {
+        if (!ctx->event_pool.empty()) {
+            ev = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            HIP_TRY(ctx, hipEventCreate(&ev.first));
+            HIP_TRY(ctx, hipEventCreate(&ev.second));
+        }
+        HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
+    }
+    hipError_t e = (hipError_t)launch_render(p, variant, (void*)ctx->stream);
+    if (e != hipSuccess) return fail_hip(ctx, e, "render kernel launch");
+    if (ctx->timing) {
+        HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
+        ctx->events.push_back(ev);
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RTX950_ABI_VERSION; }
+
+int rt_ctx_create(int device, rt_ctx** out_ctx)
+{
+    if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "out_ctx is null");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(nullptr, RT_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    rt_ctx* c = new rt_ctx();
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail_hip(nullptr, e, "hipStreamCreateWithFlags");
+    }
+    e = hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail_hip(nullptr, e, "hipMalloc(counters)");
+    }
+    *out_ctx = c;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(rt_ctx* ctx)
+{
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    (void)hipFree(ctx->d_fb);
+    for (auto& b : ctx->d_dbg) (void)hipFree(b);
+    (void)hipFree(ctx->d_counters);
+    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : ctx->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
+
+int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_sphere* spheres, size_t n_spheres,
+                    const rt_material* materials, size_t n_materials, const uint8_t* atlas_rgb8, size_t n_textures,
+                    uint32_t tex_w, uint32_t tex_h, uint32_t sprite)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
+    if ((n_cubes && !cubes) || (n_spheres && !spheres)) return fail(ctx, RT_ERR_INVALID_ARG, "object array is null");
+    if (!materials || n_materials == 0) return fail(ctx, RT_ERR_INVALID_ARG, "material table is empty");
+    if (n_cubes > 0x7FFFFFFFu || n_spheres > 0x7FFFFFFFu) return fail(ctx, RT_ERR_UNSUPPORTED, "too many objects");
+    if (n_textures && (!atlas_rgb8 || tex_w == 0 || tex_h == 0 || sprite == 0)) return fail(ctx, RT_ERR_INVALID_ARG, "bad atlas description");
+    if (n_textures && ((uint64_t)n_textures * tex_w * tex_h > 0x3FFFFFFFull)) return fail(ctx, RT_ERR_UNSUPPORTED, "atlas too large");
+    for (size_t i = 0; i < n_materials; ++i) {
+        if (materials[i].texture != RT_TEXTURE_NONE && (materials[i].texture < 0 || (size_t)materials[i].texture >= n_textures))
+            return fail(ctx, RT_ERR_INVALID_ARG, "material references a texture outside the atlas");
+    }
+    for (size_t i = 0; i < n_cubes; ++i)
+        if (cubes[i].material >= n_materials) return fail(ctx, RT_ERR_INVALID_ARG, "cube references a material outside the table");
+    for (size_t i = 0; i < n_spheres; ++i)
+        if (spheres[i].material >= n_materials) return fail(ctx, RT_ERR_INVALID_ARG, "sphere references a material outside the table");
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+
+    std::vector<CubeRec> hc(n_cubes);
+    std::vector<uint32_t> hcm(n_cubes);
+    float bmax = 0.0f;
+    bool fast_ok = true;
+    auto check_bound = [&](float b) {
+        float a = std::fabs(b);
+        if (!(a == 0.0f || (a >= 0x1p-30f && a <= 0x1p20f))) fast_ok = false;  // also catches NaN/inf
+        if (a > bmax) bmax = a;
+    };
+    for (size_t i = 0; i < n_cubes; ++i) {
+        const float half = cubes[i].size / 2.0f;  // cube.rs:52
+        CubeRec& r = hc[i];
+        r.minx = cubes[i].center.x - half; r.maxx = cubes[i].center.x + half;
+        r.miny = cubes[i].center.y - half; r.maxy = cubes[i].center.y + half;
+        r.minz = cubes[i].center.z - half; r.maxz = cubes[i].center.z + half;
+        r.id = cubes[i].id;
+        r.size = cubes[i].size;
+        hcm[i] = cubes[i].material;
+        check_bound(r.minx); check_bound(r.maxx); check_bound(r.miny);
+        check_bound(r.maxy); check_bound(r.minz); check_bound(r.maxz);
+    }
+    std::vector<SphereRec> hs(n_spheres);
+    std::vector<SphereMeta> hsm(n_spheres);
+    for (size_t i = 0; i < n_spheres; ++i) {
+        hs[i] = SphereRec{spheres[i].center.x, spheres[i].center.y, spheres[i].center.z, spheres[i].radius};
+        hsm[i] = SphereMeta{spheres[i].id, spheres[i].material};
+    }
+    std::vector<MatRec> hm(n_materials);
+    for (size_t i = 0; i < n_materials; ++i) {
+        hm[i] = MatRec{materials[i].specular, materials[i].albedo0, materials[i].albedo1, materials[i].reflectivity,
+                       materials[i].transparency, materials[i].refractive_index, materials[i].diffuse_0rgb & 0x00FFFFFFu,
+                       materials[i].texture};
+    }
+    const size_t texels = n_textures * (size_t)tex_w * tex_h;
+    std::vector<uint32_t> ha(texels);
+    for (size_t t = 0; t < texels; ++t)
+        ha[t] = ((uint32_t)atlas_rgb8[3 * t] << 16) | ((uint32_t)atlas_rgb8[3 * t + 1] << 8) | (uint32_t)atlas_rgb8[3 * t + 2];
+
+    int rc;
+    if ((rc = upload(ctx, &ctx->d_cubes, hc)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_cube_mat, hcm)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_spheres, hs)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_sphere_meta, hsm)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_mats, hm)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_atlas, ha)) != RT_OK) return rc;
+
+    Params& b = ctx->base;
+    std::memset(&b, 0, sizeof(b));
+    b.cubes = ctx->d_cubes;
+    b.cube_mat = ctx->d_cube_mat;
+    b.spheres = ctx->d_spheres;
+    b.sphere_meta = ctx->d_sphere_meta;
+    b.mats = ctx->d_mats;
+    b.atlas = ctx->d_atlas;
+    b.n_cubes = (uint32_t)n_cubes;
+    b.n_spheres = (uint32_t)n_spheres;
+    b.tex_w = n_textures ? tex_w : 1u;
+    b.tex_h = n_textures ? tex_h : 1u;
+    b.sprite = (float)sprite;  // `sprite_size as f32`, texture.rs:179
+    b.bound_max = bmax;
+    b.fast_ok = fast_ok ? 1u : 0u;
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out_0rgb, const rt_debug_planes* dbg_device)
+{
+    int rc = check_frame(ctx, frame);
+    if (rc != RT_OK) return rc;
+    if (!d_out_0rgb) return fail(ctx, RT_ERR_INVALID_ARG, "output pointer is null");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Params p;
+    fill_frame(ctx, frame, p);
+    p.out = d_out_0rgb;
+    int variant = kVariantRender;
+    if (dbg_device && (dbg_device->hit_cube || dbg_device->hit_sphere || dbg_device->tree_hash)) {
+        p.hit_cube = dbg_device->hit_cube;
+        p.hit_sphere = dbg_device->hit_sphere;
+        p.tree_hash = dbg_device->tree_hash;
+        variant = kVariantDebug;
+    }
+    return launch_timed(ctx, p, variant);
+}
+
+int rt_render(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_0rgb, const rt_debug_planes* dbg_host)
+{
+    int rc = check_frame(ctx, frame);
+    if (rc != RT_OK) return rc;
+    if (!out_0rgb) return fail(ctx, RT_ERR_INVALID_ARG, "output pointer is null");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)(frame->y1 - frame->y0) * frame->width;
+    if ((rc = ensure(ctx, &ctx->d_fb, &ctx->fb_capacity, npx)) != RT_OK) return rc;
+    rt_debug_planes dev{nullptr, nullptr, nullptr};
+    uint32_t* host_planes[3] = {nullptr, nullptr, nullptr};
+    if (dbg_host) {
+        host_planes[0] = dbg_host->hit_cube;
+        host_planes[1] = dbg_host->hit_sphere;
+        host_planes[2] = dbg_host->tree_hash;
+        for (int k = 0; k < 3; ++k) {
+            if (!host_planes[k]) continue;
+            if ((rc = ensure(ctx, &ctx->d_dbg[k], &ctx->dbg_capacity[k], npx)) != RT_OK) return rc;
+        }
+        dev.hit_cube = host_planes[0] ? ctx->d_dbg[0] : nullptr;
+        dev.hit_sphere = host_planes[1] ? ctx->d_dbg[1] : nullptr;
+        dev.tree_hash = host_planes[2] ? ctx->d_dbg[2] : nullptr;
+    }
+    if ((rc = rt_render_device(ctx, frame, ctx->d_fb, &dev)) != RT_OK) return rc;
+    // the single read-back
+    HIP_TRY(ctx, hipMemcpyAsync(out_0rgb, ctx->d_fb, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    for (int k = 0; k < 3; ++k)
+        if (host_planes[k])
+            HIP_TRY(ctx, hipMemcpyAsync(host_planes[k], ctx->d_dbg[k], npx * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_count_rays(rt_ctx* ctx, const rt_frame* frame, rt_counters* out)
+{
+    int rc = check_frame(ctx, frame);
+    if (rc != RT_OK) return rc;
+    if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "out is null");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Params p;
+    fill_frame(ctx, frame, p);
+    p.counters = ctx->d_counters;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    hipError_t e = (hipError_t)launch_render(p, kVariantCount, (void*)ctx->stream);
+    if (e != hipSuccess) return fail_hip(ctx, e, "count kernel launch");
+    unsigned long long h[5];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out->nearest_rays = h[0];
+    out->shadow_rays = h[1];
+    out->cube_tests = h[2];
+    out->sphere_tests = h[3];
+    out->shaded_hits = h[4];
+    return RT_OK;
+}
+
+int rt_enable_timing(rt_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
+    ctx->timing = enable != 0;
+    return RT_OK;
+}
+
+int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches)
+{
+    if (!ctx || !out_avg_ms || !out_launches) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    for (auto& ev : ctx->events) {
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+    }
+    *out_launches = (uint32_t)ctx->events.size();
+    *out_avg_ms = ctx->events.empty() ? 0.0 : total / (double)ctx->events.size();
+    for (auto& ev : ctx->events) ctx->event_pool.push_back(ev);
+    ctx->events.clear();
+    return RT_OK;
+}
+
+int rt_get_stream(rt_ctx* ctx, void** out_hip_stream)
+{
+    if (!ctx || !out_hip_stream) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
+    *out_hip_stream = (void*)ctx->stream;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// rtx950_device.h — device-side data layout shared by the kernels and the C-ABI host code.
+//
+// HBM layout (all read-only during a launch, all tiny next to 288 GB; the only per-pixel HBM
+// traffic is the 4 B/px framebuffer store and the occasional texel gather):
+//   cubes    : n_cubes  x CubeRec (32 B, one s_load_dwordx8 per ray-cube test, wave-uniform)
+//   cube_mat : n_cubes  x u32 material index (read once per winning hit)
+//   spheres  : n_spheres x SphereRec (16 B) + sphere_meta (id, material)
+//   mats     : n_materials x MatRec (32 B)
+//   atlas    : n_textures x tex_w*tex_h packed 0x00RRGGBB texels (row-major, idx = y*w + x,
+//              the layout of reference src/texture.rs:151-161)
+#pragma once
+#include <stdint.h>
+
+namespace rtx950 {
+
+// reference src/cube.rs:13-25: bounds (min,max), size, id.  Stored as (min,max) pairs per axis so a
+// wave-uniform 64-bit SGPR pair feeds one packed FMA.
+struct CubeRec {
+    float minx, maxx;
+    float miny, maxy;
+    float minz, maxz;
+    uint32_t id;
+    float size;
+};
+static_assert(sizeof(CubeRec) == 32, "CubeRec must be one dwordx8");
+
+// reference src/sphere.rs:10-15
+struct SphereRec {
+    float cx, cy, cz, radius;
+};
+struct SphereMeta {
+    uint32_t id, material;
+};
+
+// reference src/material.rs:4-18
+struct MatRec {
+    float specular, albedo0, albedo1, reflectivity;
+    float transparency, ior;
+    uint32_t diffuse_0rgb;
+    int32_t texture;
+};
+static_assert(sizeof(MatRec) == 32, "MatRec must be two dwordx4");
+
+// reference src/light.rs:5-9
+struct LightRec {
+    float px, py, pz;
+    uint32_t color_0rgb;
+    float intensity;
+};
+
+constexpr int kMaxLights = 16;
+
+struct Params {
+    // ---- scene (device pointers)
+    const CubeRec* cubes;
+    const uint32_t* cube_mat;
+    const SphereRec* spheres;
+    const SphereMeta* sphere_meta;
+    const MatRec* mats;
+    const uint32_t* atlas;
+    uint32_t n_cubes, n_spheres;
+    uint32_t tex_w, tex_h;
+    float sprite;
+    float bound_max;   // max |coordinate| over all cube bounds (filter tolerance)
+    uint32_t fast_ok;  // 1 if every cube bound is 0 or has magnitude in [2^-30, 2^20]
+    // ---- frame
+    float eye[3], right[3], up[3], fwd[3];  // camera basis, reference src/camera.rs:34-36 (hoisted)
+    uint32_t width, height, y0, y1;
+    float ambient;
+    uint32_t sky;
+    uint32_t max_depth;
+    uint32_t n_lights;
+    LightRec lights[kMaxLights];
+    // ---- outputs (device pointers; band-relative, (y1-y0)*width entries each)
+    uint32_t* out;
+    uint32_t* hit_cube;
+    uint32_t* hit_sphere;
+    uint32_t* tree_hash;
+    unsigned long long* counters;  // 5 x u64, rt_counters order
+};
+
+enum KernelVariant { kVariantRender = 0, kVariantDebug = 1, kVariantCount = 2 };
+
+// Launches the render kernel for rows [y0,y1) on `stream` (hipStream_t passed as void*).
+// Returns a hipError_t as int.
+int launch_render(const Params& p, int variant, void* stream);
+
+}  // namespace rtx950
