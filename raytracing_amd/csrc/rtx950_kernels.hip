@@ -46,13 +46,20 @@ DEV uint32_t hmix(uint32_t h, uint32_t v) { return (h ^ v) * kHashPrime; }
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+// NB: never apply __builtin_bit_cast directly to a vector element (`bit_cast(float, v[k])`): hipcc
+// (ROCm 7.2) then reads element 0 for every k.  Copy the element to a scalar first.
+DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 DEV CubeRec load_cube_uniform(const CubeRec* base, uint32_t i)
 {
-    const f32x8 v = ((KCONST f32x8*)base)[i];
+    const u32x8 v = ((KCONST u32x8*)base)[i];
+    const uint32_t e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3], e4 = v[4], e5 = v[5], e6 = v[6], e7 = v[7];
     CubeRec c;
-    c.minx = v[0]; c.maxx = v[1]; c.miny = v[2]; c.maxy = v[3]; c.minz = v[4]; c.maxz = v[5];
-    c.id = __builtin_bit_cast(uint32_t, v[6]);
-    c.size = v[7];
+    c.minx = u2f(e0); c.maxx = u2f(e1);
+    c.miny = u2f(e2); c.maxy = u2f(e3);
+    c.minz = u2f(e4); c.maxz = u2f(e5);
+    c.id = e6;
+    c.size = u2f(e7);
     return c;
 }
 DEV SphereRec load_sphere_uniform(const SphereRec* base, uint32_t i)
