@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the MI355X render path (BASELINE.json metric) on N GPUs of one node.
+
+A step = one frame of the workload rendered through the C-ABI (rt_render_device_part): at N>1 the
+frame's 16-row blocks are dealt round-robin to the ranks (strong scaling, total work fixed) and each
+rank's compact band is gathered to GPU0 over RCCL/xGMI inside the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  value = unique rays of the frame (nearest-hit + shadow list traversals,
+SURVEY.md section 8(d)) x K / max-over-ranks wall time.  roofline: algorithmic FP32 ops
+(26/cube test + 25/sphere test + 60 x lights/shaded hit) of rank 0's launch / its HIP-event time,
+against the 157.3 TFLOP/s FP32 vector peak.  cpu_baseline: the oracle (reference algorithm,
+per-light re-casting, all host threads) on a bounded row sample of the same frame, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene factory kwargs, width, height)
+    "minecraft_4k": ("default", {}, 3840, 2160),
+    "minecraft_water_4k": ("default", {"with_water": True}, 3840, 2160),
+    "minecraft_1080p": ("default", {}, 1920, 1080),
+    "minecraft_720p": ("default", {}, 1080, 720),
+    "synthetic_4k": ("synthetic", {}, 3840, 2160),
+    "minecraft_8k": ("default", {}, 7680, 4320),
+}
+
+PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
+PEAK_LANE_OPS_T = 39.3       # 256 CU x 64 lanes x 2.4 GHz: one non-packed, non-FMA op per lane-clock
+
+
+def algorithmic_flops(c, n_lights):
+    """26 FP32 ops per ray-cube test, 25 per ray-sphere test, ~60 per shaded hit per light."""
+    return 26.0 * c.cube_tests + 25.0 * c.sphere_tests + 60.0 * n_lights * c.shaded_hits
+
+
+def make_scene(rt, kind, kwargs):
+    return rt.default_scene(**kwargs) if kind == "default" else rt.synthetic_scene(**kwargs)
+
+
+def cpu_baseline(scene, width, height, target_s, max_threads):
+    """Reference algorithm on the host (oracle, literal mode) over rows 0, step, 2*step, ... of the frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    O = orc.OracleScene(scene)
+    frame = scene.frame(width, height)
+    threads = max(1, min(max_threads, len(os.sched_getaffinity(0))))
+    step = max(1, height // 24)
+    t0 = time.perf_counter()
+    _, _, cnt, used = O.render(frame, reuse_secondary=False, row_step=step, threads=threads)
+    t_probe = time.perf_counter() - t0
+    # scale the sample so that it takes about target_s seconds
+    want_rows = max(1.0, (height / step) * (target_s / max(t_probe, 1e-3)))
+    step2 = max(1, int(round(height / min(want_rows, height))))
+    if step2 != step:
+        t0 = time.perf_counter()
+        _, _, cnt, used = O.render(frame, reuse_secondary=False, row_step=step2, threads=threads)
+        t_probe = time.perf_counter() - t0
+        step = step2
+    rays = cnt.nearest_rays + cnt.shadow_rays  # literal mode: what the reference casts
+    n_rows = (height + step - 1) // step
+    return {
+        "value": rays / t_probe / 1e6,
+        "unit": "Mrays/s",
+        "cores": int(used),
+        "kind": "port",
+        "sample": f"rows 0::{step} ({n_rows} of {height} rows, {rays} reference rays) of the {width}x{height} frame, "
+                  f"{t_probe:.2f} s, oracle literal mode (per-light re-casting), pthreads over rows",
+        "seconds": t_probe,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="minecraft_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target size of the CPU baseline sample; 0 disables it")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raytracing_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (there is no CPU rendering path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    kind, kwargs, W, H = WORKLOADS[args.workload]
+    scene = make_scene(rt, kind, kwargs)
+    ctx = rt.Context(local_rank)
+    ctx.upload(scene)
+    frame = scene.frame(W, H)
+    n_lights = len(scene.lights)
+
+    my_rows = rt.part_rows(H, world, rank)
+    max_rows = max(rt.part_rows(H, world, r) for r in range(world))
+    out = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)  # padded so every rank sends the same size
+    gather_list = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)  # order the gather after the render on the library's stream
+
+    def step():
+        ctx.render_device(frame, out.data_ptr(), n_parts=world, part=rank)
+        if world > 1:
+            with torch.cuda.stream(ext):
+                dist.gather(out, gather_list, dst=0)
+
+    def sync():
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ctx.enable_timing(True)
+    ctx.kernel_time_ms()  # drop anything recorded so far
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_n = ctx.kernel_time_ms()
+    ctx.enable_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        km = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        km_list = [torch.zeros_like(km) for _ in range(world)]
+        dist.all_gather(km_list, km)
+        kern_all = [float(x.item()) for x in km_list]
+    else:
+        kern_all = [kern_ms]
+
+    # ---- accounting (outside the timed region)
+    result = None
+    if rank == 0:
+        total = ctx.count_rays(frame)
+        mine = ctx.count_rays(frame, n_parts=world, part=0) if world > 1 else total
+        rays_uniq, rays_ref = total.rays, total.ref_rays
+        ms_per_step = elapsed / args.steps * 1e3
+        flops_launch = algorithmic_flops(mine, n_lights)
+        achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        result = {
+            "metric": "Mrays/s (primary+shadow+secondary, unique rays)",
+            "value": rays_uniq * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "reference default diorama (platform materials pinned by PCG32 0xC0FFEE, reference textures baked to RGB8)"
+                    if kind == "default" else "synthetic voxel world, PCG32 0x5EED5EED",
+            "config": {
+                "workload": args.workload, "width": W, "height": H, "n_cubes": scene.n_cubes, "n_spheres": scene.n_spheres,
+                "n_lights": n_lights, "max_depth": 3,
+                "partition": f"16-row blocks round-robin over {world} GPU(s), compact bands gathered to GPU0 (RCCL)" if world > 1
+                             else "whole frame on one GPU",
+                "rays_per_frame_unique": rays_uniq, "rays_per_frame_reference": rays_ref,
+                "mrays_per_s_reference_accounting": rays_ref * args.steps / elapsed / 1e6,
+                "cube_tests_per_frame": int(total.cube_tests), "sphere_tests_per_frame": int(total.sphere_tests),
+                "kernel_ms_per_rank": kern_all,
+            },
+            "roofline": {
+                "bound": "valu_fp32", "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": None,
+                "kernel": "render_kernel<false,false>", "kernel_avg_ms": kern_ms, "launches_timed": kern_n,
+                "algorithmic_flops_per_launch": flops_launch,
+                "frac_of_nonfma_lane_op_ceiling": achieved_tf / PEAK_LANE_OPS_T,
+                "note": "algorithmic FP32 ops: 26/ray-cube test + 25/ray-sphere test + 60*lights/shaded hit (SURVEY 8d), rank 0's launch",
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            cb = cpu_baseline(scene, W, H, args.cpu_seconds, args.cpu_threads)
+            result["cpu_baseline"] = cb
+            result["config"]["gpu_over_cpu_reference_accounting"] = (rays_ref * args.steps / elapsed / 1e6) / cb["value"]
+        if world == 1 and args.extra:
+            extra = {}
+            for name in ("minecraft_1080p", "minecraft_water_4k"):
+                k2, kw2, w2, h2 = WORKLOADS[name]
+                sc2 = make_scene(rt, k2, kw2)
+                ctx.upload(sc2)
+                f2 = sc2.frame(w2, h2)
+                o2 = torch.zeros((h2, w2), dtype=torch.int32, device=dev)
+                for _ in range(2):
+                    ctx.render_device(f2, o2.data_ptr())
+                ctx.sync()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    ctx.render_device(f2, o2.data_ptr())
+                ctx.sync()
+                dt = (time.perf_counter() - t1) / 10
+                c2 = ctx.count_rays(f2)
+                extra[name] = {"ms_per_frame": dt * 1e3, "mrays_per_s": c2.rays / dt / 1e6, "rays_per_frame_unique": c2.rays}
+            result["config"]["extra"] = extra
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,13 @@ typedef struct rt_counters {
     uint64_t cube_tests;      /* executed Cube::ray_intersect calls (early exit honoured)    */
     uint64_t sphere_tests;    /* executed Sphere::ray_intersect calls                        */
     uint64_t shaded_hits;     /* nearest-hit queries that found an object                    */
+    /* the same five quantities as the REFERENCE algorithm executes them: a ray-tree node at
+     * depth k runs n_lights^k times there because the recursion sits inside the light fold */
+    uint64_t ref_nearest_rays;
+    uint64_t ref_shadow_rays;
+    uint64_t ref_cube_tests;
+    uint64_t ref_sphere_tests;
+    uint64_t ref_shaded_hits;
 } rt_counters;
 
 typedef struct rt_ctx rt_ctx;
@@ -190,6 +197,19 @@ int rt_render(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_0rgb,
 int rt_render_device(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out_0rgb,
                      const rt_debug_planes* dbg_device);
 
+/* Scanline-interleaved partition of rows [y0,y1) for multi-GPU load balance (sky rows are cheap,
+ * diorama rows are not): the band is cut into 16-row blocks and part `part` of `n_parts` renders
+ * blocks part, part+n_parts, part+2*n_parts, ...  The output is COMPACT: the part's blocks are
+ * stored one after another (rt_part_rows gives the row count), so each GPU's buffer is one
+ * contiguous message for the gather to GPU0.  n_parts = 1 is rt_render_device.  Debug planes use
+ * the same compact layout.  No reference counterpart (the reference has one address space; its
+ * pixel loop is reference src/render.rs:248-306). */
+int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part,
+                          uint32_t* d_out_0rgb, const rt_debug_planes* dbg_device);
+
+/* Number of rows part `part` of `n_parts` holds for a band of `rows` rows (16-row blocks). */
+uint32_t rt_part_rows(uint32_t rows, uint32_t n_parts, uint32_t part);
+
 /* Wait for all work enqueued on the context's stream.  No reference counterpart (the reference
  * is synchronous). */
 int rt_sync(rt_ctx* ctx);
@@ -198,6 +218,8 @@ int rt_sync(rt_ctx* ctx);
  * ray / test counters.  No reference counterpart; used for the Mrays/s metric and checked
  * against the oracle's counters in tests. */
 int rt_count_rays(rt_ctx* ctx, const rt_frame* frame, rt_counters* out);
+/* Same, restricted to interleaved part `part` of `n_parts` (see rt_render_device_part). */
+int rt_count_rays_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, rt_counters* out);
 
 /* Average device time, in milliseconds, of the render kernel launches issued since the last call
  * (measured with HIP events on the context's stream), and their number.  No reference counterpart

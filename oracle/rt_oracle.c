@@ -585,7 +585,8 @@ int orc_render(const orc_scene* S, const rt_frame* F, uint32_t* out_band, const 
     worker_main(&ws[0]);
     for (int t = 1; t < n_threads; ++t) pthread_join(th[t], NULL);
     if (counters_out) {
-        memset(counters_out, 0, sizeof(*counters_out));
+        memset(counters_out, 0, sizeof(*counters_out)); /* only the first five fields are filled: in
+            literal mode they are the reference's counts, in reuse mode the unique counts */
         for (int t = 0; t < n_threads; ++t) {
             counters_out->nearest_rays += ws[t].counters.nearest_rays;
             counters_out->shadow_rays += ws[t].counters.shadow_rays;

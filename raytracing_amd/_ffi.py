@@ -86,7 +86,24 @@ class Counters(C.Structure):
         ("cube_tests", C.c_uint64),
         ("sphere_tests", C.c_uint64),
         ("shaded_hits", C.c_uint64),
+        ("ref_nearest_rays", C.c_uint64),
+        ("ref_shadow_rays", C.c_uint64),
+        ("ref_cube_tests", C.c_uint64),
+        ("ref_sphere_tests", C.c_uint64),
+        ("ref_shaded_hits", C.c_uint64),
     ]
+
+    _BASE = ("nearest_rays", "shadow_rays", "cube_tests", "sphere_tests", "shaded_hits")
+
+    def uniq_dict(self):
+        return {k: int(getattr(self, k)) for k in self._BASE}
+
+    def ref_dict(self):
+        return {k: int(getattr(self, "ref_" + k)) for k in self._BASE}
+
+    @property
+    def ref_rays(self):
+        return int(self.ref_nearest_rays + self.ref_shadow_rays)
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -109,8 +126,11 @@ ABI_SYMBOLS = {
     ),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_void_p, C.POINTER(DebugPlanes)]),
     "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_void_p, C.POINTER(DebugPlanes)]),
+    "rt_render_device_part": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(DebugPlanes)]),
+    "rt_part_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "rt_sync": (C.c_int, [C.c_void_p]),
     "rt_count_rays": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.POINTER(Counters)]),
+    "rt_count_rays_part": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_uint32, C.c_uint32, C.POINTER(Counters)]),
     "rt_kernel_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "rt_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -182,20 +182,20 @@ class Context:
                                         C.byref(dbg) if dbg is not None else None))
         return (out, planes) if debug else out
 
-    def render_device(self, frame: Frame, d_out_ptr: int, d_hit_cube=0, d_hit_sphere=0, d_tree_hash=0):
-        """rt_render_device: asynchronous render into device memory (raw pointers)."""
+    def render_device(self, frame: Frame, d_out_ptr: int, d_hit_cube=0, d_hit_sphere=0, d_tree_hash=0, n_parts=1, part=0):
+        """rt_render_device[_part]: asynchronous render into device memory (raw pointers)."""
         dbg = None
         if d_hit_cube or d_hit_sphere or d_tree_hash:
             dbg = DebugPlanes(d_hit_cube or None, d_hit_sphere or None, d_tree_hash or None)
-        self._check(self._lib.rt_render_device(self._ctx, C.byref(frame), C.c_void_p(d_out_ptr),
-                                               C.byref(dbg) if dbg is not None else None))
+        self._check(self._lib.rt_render_device_part(self._ctx, C.byref(frame), n_parts, part, C.c_void_p(d_out_ptr),
+                                                    C.byref(dbg) if dbg is not None else None))
 
     def sync(self):
         self._check(self._lib.rt_sync(self._ctx))
 
-    def count_rays(self, frame: Frame) -> Counters:
+    def count_rays(self, frame: Frame, n_parts=1, part=0) -> Counters:
         c = Counters()
-        self._check(self._lib.rt_count_rays(self._ctx, C.byref(frame), C.byref(c)))
+        self._check(self._lib.rt_count_rays_part(self._ctx, C.byref(frame), n_parts, part, C.byref(c)))
         return c
 
     def enable_timing(self, on=True):
@@ -210,6 +210,19 @@ class Context:
         s = C.c_void_p()
         self._check(self._lib.rt_get_stream(self._ctx, C.byref(s)))
         return s.value or 0
+
+
+def part_rows(rows, n_parts, part):
+    """Rows held by interleaved part `part` of `n_parts` (16-row blocks), see rt_render_device_part."""
+    return int(_ffi.lib().rt_part_rows(rows, n_parts, part))
+
+
+def part_row_indices(rows, n_parts, part, block=16):
+    """Band-relative row numbers of that part, in the order of its compact buffer."""
+    idx = []
+    for b in range(part, (rows + block - 1) // block, n_parts):
+        idx.extend(range(b * block, min(rows, (b + 1) * block)))
+    return np.asarray(idx, dtype=np.int64)
 
 
 def render(scene: Scene, width, height, device=0, debug=False):

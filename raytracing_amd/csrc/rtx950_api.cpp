@@ -137,6 +137,8 @@ void fill_frame(const rt_ctx* ctx, const rt_frame* f, Params& p)
     p.height = f->height;
     p.y0 = f->y0;
     p.y1 = f->y1;
+    p.n_parts = 1u;
+    p.part = 0u;
     p.ambient = f->ambient_light;
     p.sky = f->sky_0rgb & 0x00FFFFFFu;
     p.max_depth = f->max_depth;
@@ -210,7 +212,7 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
         delete c;
         return fail_hip(nullptr, e, "hipStreamCreateWithFlags");
     }
-    e = hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long));
+    e = hipMalloc((void**)&c->d_counters, 16 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
@@ -326,14 +328,35 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     return RT_OK;
 }
 
+uint32_t rt_part_rows(uint32_t rows, uint32_t n_parts, uint32_t part)
+{
+    if (n_parts == 0u || part >= n_parts) return 0u;
+    const uint32_t blocks = (rows + kRowBlock - 1u) / kRowBlock;
+    uint32_t total = 0u;
+    for (uint32_t b = part; b < blocks; b += n_parts) {
+        const uint32_t first = b * kRowBlock;
+        total += (rows - first < kRowBlock) ? rows - first : kRowBlock;
+    }
+    return total;
+}
+
 int rt_render_device(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out_0rgb, const rt_debug_planes* dbg_device)
+{
+    return rt_render_device_part(ctx, frame, 1u, 0u, d_out_0rgb, dbg_device);
+}
+
+int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, uint32_t* d_out_0rgb,
+                          const rt_debug_planes* dbg_device)
 {
     int rc = check_frame(ctx, frame);
     if (rc != RT_OK) return rc;
     if (!d_out_0rgb) return fail(ctx, RT_ERR_INVALID_ARG, "output pointer is null");
+    if (n_parts == 0u || part >= n_parts) return fail(ctx, RT_ERR_INVALID_ARG, "need 0 <= part < n_parts");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Params p;
     fill_frame(ctx, frame, p);
+    p.n_parts = n_parts;
+    p.part = part;
     p.out = d_out_0rgb;
     int variant = kVariantRender;
     if (dbg_device && (dbg_device->hit_cube || dbg_device->hit_sphere || dbg_device->tree_hash)) {
@@ -385,19 +408,24 @@ int rt_sync(rt_ctx* ctx)
     return RT_OK;
 }
 
-int rt_count_rays(rt_ctx* ctx, const rt_frame* frame, rt_counters* out)
+int rt_count_rays(rt_ctx* ctx, const rt_frame* frame, rt_counters* out) { return rt_count_rays_part(ctx, frame, 1u, 0u, out); }
+
+int rt_count_rays_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, rt_counters* out)
 {
     int rc = check_frame(ctx, frame);
     if (rc != RT_OK) return rc;
     if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "out is null");
+    if (n_parts == 0u || part >= n_parts) return fail(ctx, RT_ERR_INVALID_ARG, "need 0 <= part < n_parts");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Params p;
     fill_frame(ctx, frame, p);
+    p.n_parts = n_parts;
+    p.part = part;
     p.counters = ctx->d_counters;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
     hipError_t e = (hipError_t)launch_render(p, kVariantCount, (void*)ctx->stream);
     if (e != hipSuccess) return fail_hip(ctx, e, "count kernel launch");
-    unsigned long long h[5];
+    unsigned long long h[10];
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out->nearest_rays = h[0];
@@ -405,6 +433,11 @@ int rt_count_rays(rt_ctx* ctx, const rt_frame* frame, rt_counters* out)
     out->cube_tests = h[2];
     out->sphere_tests = h[3];
     out->shaded_hits = h[4];
+    out->ref_nearest_rays = h[5];
+    out->ref_shadow_rays = h[6];
+    out->ref_cube_tests = h[7];
+    out->ref_sphere_tests = h[8];
+    out->ref_shaded_hits = h[9];
     return RT_OK;
 }
 

@@ -49,6 +49,7 @@ struct LightRec {
 };
 
 constexpr int kMaxLights = 16;
+constexpr uint32_t kRowBlock = 16;  // rows per workgroup tile and per interleave block
 
 struct Params {
     // ---- scene (device pointers)
@@ -66,6 +67,7 @@ struct Params {
     // ---- frame
     float eye[3], right[3], up[3], fwd[3];  // camera basis, reference src/camera.rs:34-36 (hoisted)
     uint32_t width, height, y0, y1;
+    uint32_t n_parts, part;  // 16-row blocks b with b % n_parts == part are rendered, output compact
     float ambient;
     uint32_t sky;
     uint32_t max_depth;
@@ -76,7 +78,7 @@ struct Params {
     uint32_t* hit_cube;
     uint32_t* hit_sphere;
     uint32_t* tree_hash;
-    unsigned long long* counters;  // 5 x u64, rt_counters order
+    unsigned long long* counters;  // 10 x u64, rt_counters order
 };
 
 enum KernelVariant { kVariantRender = 0, kVariantDebug = 1, kVariantCount = 2 };

@@ -116,9 +116,21 @@ DEV Col col_add(Col a, Col b)
 }
 
 // ---------------------------------------------------------------- counters (count variant only)
-struct Counters {
+struct Counters {  // per ray-tree node
     uint32_t nearest_rays, shadow_rays, cube_tests, sphere_tests, shaded_hits;
 };
+struct Totals {  // per lane: [0..4] unique work, [5..9] the reference's n_lights^depth-weighted work
+    unsigned long long v[10];
+};
+DEV void totals_add(Totals& t, const Counters& c, unsigned long long w)
+{
+    const uint32_t a[5] = {c.nearest_rays, c.shadow_rays, c.cube_tests, c.sphere_tests, c.shaded_hits};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        t.v[k] += a[k];
+        t.v[5 + k] += (unsigned long long)a[k] * w;
+    }
+}
 
 // ---------------------------------------------------------------- per-ray precomputation for the cube filter
 struct RayPre {
@@ -435,7 +447,7 @@ DEV float shadow_query(const Params& P, V3 origin, V3 light_pos, uint32_t impact
 // equals min(255, sum_l DS_l + L*(refl*k_r) + L*(refr*k_t)) per channel and can be evaluated
 // after the children return.
 template <int PASS, int DEPTH, bool DBG, bool COUNT>
-DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uint32_t& hit_idx, Counters& cnt)
+DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uint32_t& hit_idx, Totals& tot)
 {
     const Col sky = col_from_hex(P.sky);
     hit_idx = kNoHit;
@@ -449,6 +461,7 @@ DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uin
         }
         uint32_t idx;
         float dist;
+        Counters cnt = {0u, 0u, 0u, 0u, 0u};
         nearest_query<PASS, COUNT>(P, o, d, idx, dist, cnt);
         hit_idx = idx;
         uint32_t h = hmix(kHashBasis, idx);
@@ -504,7 +517,7 @@ DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uin
                         const V3 co = is_refl ? refl_o : refr_o;
                         const V3 cd = is_refl ? refl_d : refr_d;
                         uint32_t ch, cidx;
-                        const Col cc = cast_ray<PASS, DEPTH + 1, DBG, COUNT>(P, co, cd, ambient, ch, cidx, cnt);
+                        const Col cc = cast_ray<PASS, DEPTH + 1, DBG, COUNT>(P, co, cd, ambient, ch, cidx, tot);
                         if (is_refl) { c_refl = cc; h_refl = ch; }
                         else { c_refr = cc; h_refr = ch; }
                     }
@@ -521,6 +534,12 @@ DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uin
                 h = hmix(h, h_refr);
             }
         }
+        if constexpr (COUNT) {
+            unsigned long long w = 1ull;  // n_lights^DEPTH: how often the reference runs this node
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) w *= P.n_lights;
+            totals_add(tot, cnt, w);
+        }
         hash = h;
         return result;
     }
@@ -535,8 +554,13 @@ __global__ __launch_bounds__(256) void render_kernel(const Params P)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t y = P.y0 + blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    Counters cnt = {0u, 0u, 0u, 0u, 0u};
+    const uint32_t ly = (wave >> 1) * 8u + (lane >> 3);
+    // interleaved parts: this launch renders 16-row blocks part, part+n_parts, ... of [y0,y1)
+    const uint32_t y = P.y0 + (blockIdx.y * P.n_parts + P.part) * kRowBlock + ly;
+    const uint32_t out_row = blockIdx.y * kRowBlock + ly;
+    Totals cnt;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) cnt.v[k] = 0ull;
     if (x < P.width && y < P.y1) {
         const float width = (float)P.width, height = (float)P.height;
         const float aspect = width / height;
@@ -558,7 +582,7 @@ __global__ __launch_bounds__(256) void render_kernel(const Params P)
         uint32_t px = (s_hex == P.sky) ? col_to_hex(cc) : s_hex;  // render.rs:308-312
         const size_t i_frame = (size_t)y * P.width + x;
         if (i_frame == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
-        const size_t i_band = (size_t)(y - P.y0) * P.width + x;
+        const size_t i_band = (size_t)out_row * P.width + x;
         if constexpr (!COUNT) {
             if (P.out) P.out[i_band] = px;
         }
@@ -570,10 +594,9 @@ __global__ __launch_bounds__(256) void render_kernel(const Params P)
     }
     if constexpr (COUNT) {
         // wave reduction, then one atomic per wave and counter
-        uint32_t vals[5] = {cnt.nearest_rays, cnt.shadow_rays, cnt.cube_tests, cnt.sphere_tests, cnt.shaded_hits};
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            unsigned long long v = vals[k];
+        for (int k = 0; k < 10; ++k) {
+            unsigned long long v = cnt.v[k];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0u && v != 0ull) atomicAdd(&P.counters[k], v);
@@ -586,7 +609,11 @@ __global__ __launch_bounds__(256) void render_kernel(const Params P)
 int launch_render(const Params& p, int variant, void* stream)
 {
     const uint32_t rows = p.y1 - p.y0;
-    dim3 grid((p.width + 15u) / 16u, (rows + 15u) / 16u, 1u);
+    const uint32_t blocks = (rows + kRowBlock - 1u) / kRowBlock;
+    if (p.n_parts == 0u || p.part >= p.n_parts) return (int)hipErrorInvalidValue;
+    if (p.part >= blocks) return (int)hipSuccess;  // this part owns no rows
+    const uint32_t my_blocks = (blocks - p.part + p.n_parts - 1u) / p.n_parts;
+    dim3 grid((p.width + 15u) / 16u, my_blocks, 1u);
     dim3 block(256u, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {

@@ -28,14 +28,14 @@ def test_default_scene_matches_oracle(gpu_ctx, oracle_mod, default_scene, w, h):
     print("colour parity", rep)
     # counters of the unique-ray accounting
     c = gpu_ctx.count_rays(f)
-    assert c.as_dict() == ocnt.as_dict()
+    assert c.uniq_dict() == ocnt.uniq_dict()
 
 
 def test_water_variant_matches_oracle(gpu_ctx, oracle_mod, water_scene):
     f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, water_scene, 480, 270)
     rep = assert_parity(gfb, gpl, ofb, opl, "minecraft+water 480x270")
     print("colour parity", rep)
-    assert gpu_ctx.count_rays(f).as_dict() == ocnt.as_dict()
+    assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
 
 
 def test_debug_and_plain_kernels_agree(gpu_ctx, default_scene):
@@ -68,7 +68,7 @@ def test_synthetic_small_matches_oracle(gpu_ctx, oracle_mod):
     rep = assert_parity(gfb, gpl, ofb, opl, "synthetic 600c/24s 320x180")
     print("colour parity", rep)
     assert (gpl["hit_sphere"] != rt.RT_NO_HIT).any(), "test scene should show spheres"
-    assert gpu_ctx.count_rays(f).as_dict() == ocnt.as_dict()
+    assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
 
 
 def test_night_and_orbit_match_oracle(gpu_ctx, oracle_mod, default_scene):
