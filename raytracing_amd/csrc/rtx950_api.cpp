@@ -25,6 +25,7 @@ struct rt_ctx {
     // scene
     bool has_scene = false;
     CubeRec* d_cubes = nullptr;
+    float* d_cube_filt = nullptr;
     uint32_t* d_cube_mat = nullptr;
     SphereRec* d_spheres = nullptr;
     SphereMeta* d_sphere_meta = nullptr;
@@ -81,6 +82,8 @@ H3 h_normalize(H3 a)
 void free_scene(rt_ctx* c)
 {
     (void)hipFree(c->d_cubes);
+    (void)hipFree(c->d_cube_filt);
+    c->d_cube_filt = nullptr;
     (void)hipFree(c->d_cube_mat);
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_sphere_meta);
@@ -265,6 +268,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
 
     std::vector<CubeRec> hc(n_cubes);
     std::vector<uint32_t> hcm(n_cubes);
+    // filter stream, padded to a multiple of 4 records (+4 so the prefetch of the last batch stays in bounds)
+    const size_t n_filt = ((n_cubes + 3) / 4) * 4 + 4;
+    std::vector<float> hf(n_filt * 4);
+    for (size_t i = 0; i < n_filt; ++i) {
+        hf[4 * i + 0] = 1e18f; hf[4 * i + 1] = -1e18f; hf[4 * i + 2] = 1e18f; hf[4 * i + 3] = 0.0f;
+    }
     float bmax = 0.0f;
     bool fast_ok = true;
     auto check_bound = [&](float b) {
@@ -281,6 +290,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
         r.id = cubes[i].id;
         r.size = cubes[i].size;
         hcm[i] = cubes[i].material;
+        hf[4 * i + 0] = cubes[i].center.x; hf[4 * i + 1] = cubes[i].center.y; hf[4 * i + 2] = cubes[i].center.z;
+        hf[4 * i + 3] = half;
         check_bound(r.minx); check_bound(r.maxx); check_bound(r.miny);
         check_bound(r.maxy); check_bound(r.minz); check_bound(r.maxz);
     }
@@ -304,6 +315,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     int rc;
     if ((rc = upload(ctx, &ctx->d_cubes, hc)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_cube_mat, hcm)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_cube_filt, hf)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_spheres, hs)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_sphere_meta, hsm)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_mats, hm)) != RT_OK) return rc;
@@ -313,6 +325,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     std::memset(&b, 0, sizeof(b));
     b.cubes = ctx->d_cubes;
     b.cube_mat = ctx->d_cube_mat;
+    b.cube_filt = ctx->d_cube_filt;
     b.spheres = ctx->d_spheres;
     b.sphere_meta = ctx->d_sphere_meta;
     b.mats = ctx->d_mats;

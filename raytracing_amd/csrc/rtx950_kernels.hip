@@ -45,6 +45,8 @@ DEV uint32_t hmix(uint32_t h, uint32_t v) { return (h ^ v) * kHashPrime; }
 // same in every lane makes hipcc emit s_load_dwordx8 / x4 / x2 (SGPR destination).
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 // NB: never apply __builtin_bit_cast directly to a vector element (`bit_cast(float, v[k])`): hipcc
@@ -61,6 +63,11 @@ DEV CubeRec load_cube_uniform(const CubeRec* base, uint32_t i)
     c.id = e6;
     c.size = u2f(e7);
     return c;
+}
+// 4 consecutive filter records (centre.xyz, half size), 64-byte aligned -> one s_load_dwordx16
+DEV f32x16 load_filt4_uniform(const float* base, uint32_t first)
+{
+    return *(KCONST f32x16*)(base + (size_t)first * 4u);
 }
 DEV SphereRec load_sphere_uniform(const SphereRec* base, uint32_t i)
 {
@@ -132,12 +139,29 @@ DEV void totals_add(Totals& t, const Counters& c, unsigned long long w)
     }
 }
 
-// ---------------------------------------------------------------- per-ray precomputation for the cube filter
+// ---------------------------------------------------------------- conservative cube filter
+// The reference tests every ray against every cube with 6 true divisions (cube.rs:90-109).  Almost
+// all of those tests fail, and a failing test contributes nothing to the output.  The filter proves
+// "fails" cheaply and sends everything it cannot prove to cube_exact.
+//
+// Per ray (once):   r_c = RN(1/d_c), c_c = -RN(o_c r_c), a_c = |r_c|, tol.
+// Per cube (centre k, half-size h; 9 VALU instructions, 4 of them packed):
+//   m_c   = fma(k_c, r_c, c_c)                      ~ (k_c - o_c)/d_c
+//   near_c = fma(h, -a_c, m_c), far_c = fma(h, a_c, m_c)   ~ the slab interval on axis c
+//   candidate  <=>  !(max3(near) - min3(far) > tol)
+// Error bound, u = 2^-24, no overflow/underflow (dir_ok/org_ok/fast_ok guarantee the ranges):
+//   reference  t = RN(RN(RN(k -+ h) - o)/d)            |t  - T| <= 3u (B+|o|)|r| (1+O(u)),  T exact
+//   filter     t~ = RN(fma(h,-+a, RN(fma(k,r,-RN(o r)))))  |t~ - T| <= 5u (B+|o|)|r| (1+O(u))
+// with B >= |k|+h the largest bound magnitude in the scene.  lo = max3 and hi = min3 each move by at
+// most the largest per-axis error E = 8u max_c (B+|o_c|)|r_c|, so lo~ - hi~ > 2E implies lo > hi, which
+// is exactly when the reference's staged slab test (cube.rs:101,113) returns None.  tol = 32u max_c(...)
+// = 2E: twice the requirement.  Rays outside the safe ranges get tol = +inf (every cube is a
+// candidate), and the negated compare makes NaN a candidate too.
 struct RayPre {
-    float rx, ry, rz;  // RN(1/d)
-    float cx, cy, cz;  // -(o*r)
+    f32x2 r_xy, c_xy, na_xy;  // (r_x,r_y), (c_x,c_y), (-a_x,-a_y)
+    f32x2 rc_z;               // (r_z, c_z)
+    f32x2 a_z_pm;             // (-a_z, +a_z)
     float tol;
-    bool safe;
 };
 
 DEV bool dir_ok(float v)
@@ -151,38 +175,38 @@ DEV bool org_ok(float v)
     return a == 0.0f || (a >= 0x1p-30f && a <= 0x1p20f);
 }
 
-// Filter error bound.  Reference: t = RN(RN(b-o)/d).  Filter: t~ = RN(fma(b, r, -RN(o*r))), r = RN(1/d).
-// With u = 2^-24 and no overflow/underflow (guaranteed by dir_ok/org_ok/fast_ok):
-//   |t~ - t| <= 5u (|b|+|o|) |r| (1 + O(u)).
-// lo = max3 of three such values and hi = min3, so lo~ - hi~ > 2*max_axis(5u (B+|o_c|)|r_c|) implies
-// lo > hi, i.e. the reference's slab test (cube.rs:101,113) rejects.  tol uses 16u > 10u.
 DEV RayPre ray_pre(const Params& P, V3 o, V3 d)
 {
     RayPre q;
-    q.safe = (P.fast_ok != 0u) && dir_ok(d.x) && dir_ok(d.y) && dir_ok(d.z) && org_ok(o.x) && org_ok(o.y) && org_ok(o.z);
-    q.rx = 1.0f / d.x;
-    q.ry = 1.0f / d.y;
-    q.rz = 1.0f / d.z;
-    q.cx = -(o.x * q.rx);
-    q.cy = -(o.y * q.ry);
-    q.cz = -(o.z * q.rz);
-    float ex = (P.bound_max + __builtin_fabsf(o.x)) * __builtin_fabsf(q.rx);
-    float ey = (P.bound_max + __builtin_fabsf(o.y)) * __builtin_fabsf(q.ry);
-    float ez = (P.bound_max + __builtin_fabsf(o.z)) * __builtin_fabsf(q.rz);
-    q.tol = 0x1p-20f * __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez));
+    const bool safe = (P.fast_ok != 0u) && dir_ok(d.x) && dir_ok(d.y) && dir_ok(d.z) && org_ok(o.x) && org_ok(o.y) && org_ok(o.z);
+    const float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;
+    const float ax = __builtin_fabsf(rx), ay = __builtin_fabsf(ry), az = __builtin_fabsf(rz);
+    q.r_xy = f32x2{rx, ry};
+    q.c_xy = f32x2{-(o.x * rx), -(o.y * ry)};
+    q.na_xy = f32x2{-ax, -ay};
+    q.rc_z = f32x2{rz, -(o.z * rz)};
+    q.a_z_pm = f32x2{-az, az};
+    const float ex = (P.bound_max + __builtin_fabsf(o.x)) * ax;
+    const float ey = (P.bound_max + __builtin_fabsf(o.y)) * ay;
+    const float ez = (P.bound_max + __builtin_fabsf(o.z)) * az;
+    q.tol = safe ? 0x1p-19f * __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) : __builtin_inff();
     return q;
 }
 
-// true  -> the cube may pass the reference slab test (go to cube_exact)
-// false -> proven miss
-DEV bool cube_filter(const CubeRec& c, const RayPre& q)
+// rec = (centre.x, centre.y, centre.z, half size), wave-uniform.
+// true -> the cube may pass the reference slab test (go to cube_exact); false -> proven miss
+DEV bool cube_filter(f32x4 rec, const RayPre& q)
 {
-    float t0x = __builtin_fmaf(c.minx, q.rx, q.cx), t1x = __builtin_fmaf(c.maxx, q.rx, q.cx);
-    float t0y = __builtin_fmaf(c.miny, q.ry, q.cy), t1y = __builtin_fmaf(c.maxy, q.ry, q.cy);
-    float t0z = __builtin_fmaf(c.minz, q.rz, q.cz), t1z = __builtin_fmaf(c.maxz, q.rz, q.cz);
-    float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
-    float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
-    return !q.safe || (lo - hi <= q.tol);
+    const f32x2 k_xy = f32x2{rec[0], rec[1]};
+    const f32x2 hh = f32x2{rec[3], rec[3]};
+    const f32x2 m_xy = __builtin_elementwise_fma(k_xy, q.r_xy, q.c_xy);
+    const float m_z = __builtin_fmaf(rec[2], q.rc_z[0], q.rc_z[1]);
+    const f32x2 near_xy = __builtin_elementwise_fma(hh, q.na_xy, m_xy);
+    const f32x2 far_xy = __builtin_elementwise_fma(hh, -q.na_xy, m_xy);
+    const f32x2 nf_z = __builtin_elementwise_fma(hh, q.a_z_pm, f32x2{m_z, m_z});
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(near_xy[0], near_xy[1]), nf_z[0]);
+    const float hi = __builtin_fminf(__builtin_fminf(far_xy[0], far_xy[1]), nf_z[1]);
+    return !(lo - hi > q.tol);
 }
 
 // reference src/cube.rs:90-145 (slab test and distance), src/lib.rs:29-35 (minmax)
@@ -352,17 +376,35 @@ DEV void nearest_query(const Params& P, V3 o, V3 d, uint32_t& best_idx, float& b
     if constexpr (PASS == PASS_CUBES) {
         const RayPre q = ray_pre(P, o, d);
         const uint32_t n = P.n_cubes;
-        for (uint32_t i = 0; i < n; ++i) {
-            const CubeRec c = load_cube_uniform(P.cubes, i);
-            if (cube_filter(c, q)) {
-                float dist;
-                if (cube_exact(c, o, d, dist)) {
-                    if (dist < best_dist) {  // strict <: lowest index wins ties, NaN never wins
-                        best_dist = dist;
-                        best_idx = i;
+        // 4 filter records (one 64-byte line, one s_load_dwordx16) per iteration; the array is padded
+        // to a multiple of 4 with far-away zero-size boxes.  One branch per batch: the exact path
+        // runs only when some lane's filter could not prove a miss.
+        f32x16 cur = load_filt4_uniform(P.cube_filt, 0u);
+        for (uint32_t base = 0; base < n; base += 4u) {
+            const uint32_t nb = base + 4u;
+            const f32x16 nxt = load_filt4_uniform(P.cube_filt, nb < n ? nb : base);  // prefetch
+            const bool c0 = cube_filter(f32x4{cur[0], cur[1], cur[2], cur[3]}, q);
+            const bool c1 = cube_filter(f32x4{cur[4], cur[5], cur[6], cur[7]}, q);
+            const bool c2 = cube_filter(f32x4{cur[8], cur[9], cur[10], cur[11]}, q);
+            const bool c3 = cube_filter(f32x4{cur[12], cur[13], cur[14], cur[15]}, q);
+            if (c0 | c1 | c2 | c3) {
+                const bool cand[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t i = base + k;
+                    if (i < n && cand[k]) {
+                        const CubeRec c = load_cube_uniform(P.cubes, i);
+                        float dist;
+                        if (cube_exact(c, o, d, dist)) {
+                            if (dist < best_dist) {  // strict <: lowest index wins ties, NaN never wins
+                                best_dist = dist;
+                                best_idx = i;
+                            }
+                        }
                     }
                 }
             }
+            cur = nxt;
         }
         if constexpr (COUNT) cnt.cube_tests += n;
     } else {
@@ -396,19 +438,42 @@ DEV float shadow_query(const Params& P, V3 origin, V3 light_pos, uint32_t impact
     if constexpr (PASS == PASS_CUBES) {
         const RayPre q = ray_pre(P, origin, dir);
         const uint32_t n = P.n_cubes;
-        for (uint32_t i = 0; i < n; ++i) {
-            const CubeRec c = load_cube_uniform(P.cubes, i);
-            const bool tested = !done && (c.id != impact_id);
-            if constexpr (COUNT) cnt.cube_tests += tested ? 1u : 0u;
-            if (tested && cube_filter(c, q)) {
-                float dist;
-                if (cube_exact(c, origin, dir, dist)) {
-                    done = true;
-                    blocker = i;
-                    sdist = dist;
+        // Same batched filter as nearest_query.  The id exclusion (render.rs:113) is applied in the
+        // rare exact path only: excluded cubes that the filter happens to pass cost one compare.
+        f32x16 cur = load_filt4_uniform(P.cube_filt, 0u);
+        for (uint32_t base = 0; base < n; base += 4u) {
+            const uint32_t nb = base + 4u;
+            const f32x16 nxt = load_filt4_uniform(P.cube_filt, nb < n ? nb : base);
+            const bool c0 = !done && cube_filter(f32x4{cur[0], cur[1], cur[2], cur[3]}, q);
+            const bool c1 = !done && cube_filter(f32x4{cur[4], cur[5], cur[6], cur[7]}, q);
+            const bool c2 = !done && cube_filter(f32x4{cur[8], cur[9], cur[10], cur[11]}, q);
+            const bool c3 = !done && cube_filter(f32x4{cur[12], cur[13], cur[14], cur[15]}, q);
+            if (c0 | c1 | c2 | c3) {
+                const bool cand[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t i = base + k;
+                    if (i < n && cand[k] && !done) {
+                        const CubeRec c = load_cube_uniform(P.cubes, i);
+                        float dist;
+                        if (c.id != impact_id && cube_exact(c, origin, dir, dist)) {
+                            done = true;
+                            blocker = i;
+                            sdist = dist;
+                        }
+                    }
                 }
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
             }
-            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+            cur = nxt;
+        }
+        if constexpr (COUNT) {
+            // executed tests = cubes before (and including) the blocker whose id differs from the impact id
+            const uint32_t limit = done ? blocker + 1u : n;
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t id = load_cube_uniform(P.cubes, i).id;
+                cnt.cube_tests += (i < limit && id != impact_id) ? 1u : 0u;
+            }
         }
     } else {
         const uint32_t n = P.n_spheres;
