@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "librtx950.so")
+# RTX950_LIB lets the A/B harness (tools/) load an experimental build of the same C-ABI; default is the in-tree library
+LIB_PATH = os.environ.get("RTX950_LIB") or os.path.join(_PKG_DIR, "librtx950.so")
 HOST_LIB_PATH = os.path.join(_PKG_DIR, "librtx950_host.so")
 BAKED_ATLAS_PATH = os.path.join(_PKG_DIR, "assets", "atlas_rgb8.bin")
 

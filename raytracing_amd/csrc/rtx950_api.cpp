@@ -26,6 +26,7 @@ struct rt_ctx {
     bool has_scene = false;
     CubeRec* d_cubes = nullptr;
     float* d_cube_filt = nullptr;
+    uint32_t* d_cube_id = nullptr;
     uint32_t* d_cube_mat = nullptr;
     SphereRec* d_spheres = nullptr;
     SphereMeta* d_sphere_meta = nullptr;
@@ -84,6 +85,8 @@ void free_scene(rt_ctx* c)
     (void)hipFree(c->d_cubes);
     (void)hipFree(c->d_cube_filt);
     c->d_cube_filt = nullptr;
+    (void)hipFree(c->d_cube_id);
+    c->d_cube_id = nullptr;
     (void)hipFree(c->d_cube_mat);
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_sphere_meta);
@@ -268,8 +271,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
 
     std::vector<CubeRec> hc(n_cubes);
     std::vector<uint32_t> hcm(n_cubes);
-    // filter stream, padded to a multiple of 4 records (+4 so the prefetch of the last batch stays in bounds)
-    const size_t n_filt = ((n_cubes + 3) / 4) * 4 + 4;
+    // cull stream, padded to a multiple of 64 records (one per lane) with far-away zero-size boxes
+    const size_t n_filt = ((n_cubes + 63) / 64) * 64 + 64;
+    std::vector<uint32_t> hid(n_filt, 0u);
     std::vector<float> hf(n_filt * 4);
     for (size_t i = 0; i < n_filt; ++i) {
         hf[4 * i + 0] = 1e18f; hf[4 * i + 1] = -1e18f; hf[4 * i + 2] = 1e18f; hf[4 * i + 3] = 0.0f;
@@ -292,6 +296,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
         hcm[i] = cubes[i].material;
         hf[4 * i + 0] = cubes[i].center.x; hf[4 * i + 1] = cubes[i].center.y; hf[4 * i + 2] = cubes[i].center.z;
         hf[4 * i + 3] = half;
+        hid[i] = cubes[i].id;
         check_bound(r.minx); check_bound(r.maxx); check_bound(r.miny);
         check_bound(r.maxy); check_bound(r.minz); check_bound(r.maxz);
     }
@@ -316,6 +321,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     if ((rc = upload(ctx, &ctx->d_cubes, hc)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_cube_mat, hcm)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_cube_filt, hf)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_cube_id, hid)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_spheres, hs)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_sphere_meta, hsm)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_mats, hm)) != RT_OK) return rc;
@@ -326,6 +332,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.cubes = ctx->d_cubes;
     b.cube_mat = ctx->d_cube_mat;
     b.cube_filt = ctx->d_cube_filt;
+    b.cube_id = ctx->d_cube_id;
     b.spheres = ctx->d_spheres;
     b.sphere_meta = ctx->d_sphere_meta;
     b.mats = ctx->d_mats;

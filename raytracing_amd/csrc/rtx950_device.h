@@ -3,8 +3,8 @@
 // HBM layout (all read-only during a launch, all tiny next to 288 GB; the only per-pixel HBM
 // traffic is the 4 B/px framebuffer store and the occasional texel gather):
 //   cubes    : n_cubes  x CubeRec (32 B, one s_load_dwordx8 per ray-cube test, wave-uniform)
-//   cube_filt: ceil4(n_cubes) x 16 B (centre, half size): the filter's stream, 4 records (one
-//              64-byte line, one s_load_dwordx16) per loop iteration, wave-uniform
+//   cube_filt: ceil64(n_cubes) x 16 B (centre, half size): the cull stream, one coalesced 1 KB wave
+//              load per 64 cubes (lane j <- record base+j); cube_id: the same for ids
 //   cube_mat : n_cubes  x u32 material index (read once per winning hit)
 //   spheres  : n_spheres x SphereRec (16 B) + sphere_meta (id, material)
 //   mats     : n_materials x MatRec (32 B)
@@ -56,7 +56,8 @@ constexpr uint32_t kRowBlock = 16;  // rows per workgroup tile and per interleav
 struct Params {
     // ---- scene (device pointers)
     const CubeRec* cubes;
-    const float* cube_filt;  // ceil4(n_cubes) x (centre.x, centre.y, centre.z, half size), 64-B aligned
+    const float* cube_filt;  // ceil64(n_cubes) x (centre.x, centre.y, centre.z, half size): lane j of a wave loads record base+j
+    const uint32_t* cube_id; // ceil64(n_cubes) x id (shadow exclusion, reference src/render.rs:113)
     const uint32_t* cube_mat;
     const SphereRec* spheres;
     const SphereMeta* sphere_meta;

@@ -5,7 +5,9 @@
 //   cast_ray()          src/render.rs:73-229    -> cast_ray<PASS,DEPTH> (recursion unrolled by template
 //                                                 depth; per-level state lives in registers)
 //   cast_shadow()       src/render.rs:44-70     -> shadow_query (inlined, list order, early exit)
-//   Cube::ray_intersect src/cube.rs:77-218      -> cube_filter (conservative, FMA) + cube_exact (IEEE)
+//   Cube::ray_intersect src/cube.rs:77-218      -> cull_test (one conservative test per cube for all 64
+//                                                 rays of a wave) + cube_slab_approx (per-ray two-sided
+//                                                 filter, FMA) + cube_exact (IEEE, only where needed)
 //                                                 + cube_resolve (face/uv for the winning hit only)
 //   Sphere::ray_intersect src/sphere.rs:25-56   -> sphere_exact
 //   Texture::get_color_of_face src/texture.rs:178-196 -> texel_of_face (packed atlas gather)
@@ -13,13 +15,16 @@
 //
 // Exactness contract.  This file is compiled with -ffp-contract=off, and HIP's default correctly
 // rounded f32 divide/sqrt stay on, so every expression below that restates a reference
-// expression rounds exactly like the reference's f32 arithmetic.  FMA is used ONLY in
-// cube_filter, whose result never reaches an output: it only proves "this cube cannot pass the
-// slab test" with an error bound, and everything it cannot prove goes through cube_exact.
+// expression rounds exactly like the reference's f32 arithmetic.  FMA is used ONLY in cull_test
+// and cube_slab_approx, whose values never reach an output: with explicit error bounds they only
+// prove "this cube cannot pass the slab test" or "it passes, and it is / is not the nearest by a
+// margin"; whatever they cannot prove goes through cube_exact, and every distance that is used
+// (hit point, shadow attenuation) is recomputed by cube_exact for the selected cube.
 //
-// Wave-uniform data.  Object records are indexed by the loop counter only, so every lane of a wave
-// reads the same record: they are loaded through the constant address space (s_load_dwordx8 into
-// SGPRs) and feed VALU instructions as scalar operands.  No LDS round trip, no VGPR copies.
+// Wave-cooperative traversal.  A wave owns an 8x8 pixel tile.  For each object-list traversal lane j
+// tests cube base+j against bounds of ALL the wave's rays (one coalesced 1 KB load + 18 FMAs per 64
+// cubes), a ballot yields the candidate bitmask, and only candidates are examined per ray, with the
+// cube broadcast from its lane by v_readlane (SGPR operands, no memory round trip, no LDS).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -148,7 +153,7 @@ DEV void totals_add(Totals& t, const Counters& c, unsigned long long w)
 // Per cube (centre k, half-size h; 9 VALU instructions, 4 of them packed):
 //   m_c   = fma(k_c, r_c, c_c)                      ~ (k_c - o_c)/d_c
 //   near_c = fma(h, -a_c, m_c), far_c = fma(h, a_c, m_c)   ~ the slab interval on axis c
-//   candidate  <=>  !(max3(near) - min3(far) > tol)
+//   lo = max3(near), hi = min3(far); decisions on lo - hi against +-tol (cube_slab_approx)
 // Error bound, u = 2^-24, no overflow/underflow (dir_ok/org_ok/fast_ok guarantee the ranges):
 //   reference  t = RN(RN(RN(k -+ h) - o)/d)            |t  - T| <= 3u (B+|o|)|r| (1+O(u)),  T exact
 //   filter     t~ = RN(fma(h,-+a, RN(fma(k,r,-RN(o r)))))  |t~ - T| <= 5u (B+|o|)|r| (1+O(u))
@@ -161,7 +166,10 @@ struct RayPre {
     f32x2 r_xy, c_xy, na_xy;  // (r_x,r_y), (c_x,c_y), (-a_x,-a_y)
     f32x2 rc_z;               // (r_z, c_z)
     f32x2 a_z_pm;             // (-a_z, +a_z)
-    float tol;
+    float tol;                // 2E: decision threshold of the two-sided filter (+inf for unsafe rays)
+    float err;                // E: bound on |approximate - reference| for tmin, tmax and the distance
+    bool unsafe;              // outside the ranges the error analysis assumes: always evaluated exactly
+    bool wild;                // non-finite or huge components: even the wave-level cull keeps every cube
 };
 
 DEV bool dir_ok(float v)
@@ -190,23 +198,36 @@ DEV RayPre ray_pre(const Params& P, V3 o, V3 d)
     const float ey = (P.bound_max + __builtin_fabsf(o.y)) * ay;
     const float ez = (P.bound_max + __builtin_fabsf(o.z)) * az;
     q.tol = safe ? 0x1p-19f * __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) : __builtin_inff();
+    q.err = 0.5f * q.tol;
+    q.unsafe = !safe;
+    // The cull (cull_test) has no division, so zero or tiny direction components are fine there: a ray
+    // whose exact line misses a box by the slack margin is rejected by the reference too, also through
+    // its +-inf arithmetic (cube.rs:90-113 with d_c = 0: both t of that axis are the same infinity, and
+    // one of the staged compares fires).  Only non-finite or huge inputs need the keep-everything path
+    // (a NaN ray passes every slab compare of the reference, which matters for shadows).
+    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    const float bigo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+    const bool finite = (d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (o.x == o.x) && (o.y == o.y) && (o.z == o.z);
+    q.wild = !(finite && big <= 0x1p40f && bigo <= 0x1p20f) || (P.fast_ok == 0u);
     return q;
 }
 
-// rec = (centre.x, centre.y, centre.z, half size), wave-uniform.
-// true -> the cube may pass the reference slab test (go to cube_exact); false -> proven miss
-DEV bool cube_filter(f32x4 rec, const RayPre& q)
+// (kx,ky,kz,h) = cube centre and half size, wave-uniform.  lo ~ tmin and hi ~ tmax of cube.rs:142-143,
+// each within q.err of the reference's value when the ray is safe.  Two-sided use:
+//   lo - hi >  tol  -> the reference's slab test fails (proven miss)
+//   lo - hi < -tol  -> it passes, and distance = (lo<0 ? hi : lo) is within err if also |lo| > err
+//   otherwise       -> undecided: evaluate cube_exact
+DEV void cube_slab_approx(float kx, float ky, float kz, float h, const RayPre& q, float& lo, float& hi)
 {
-    const f32x2 k_xy = f32x2{rec[0], rec[1]};
-    const f32x2 hh = f32x2{rec[3], rec[3]};
+    const f32x2 k_xy = f32x2{kx, ky};
+    const f32x2 hh = f32x2{h, h};
     const f32x2 m_xy = __builtin_elementwise_fma(k_xy, q.r_xy, q.c_xy);
-    const float m_z = __builtin_fmaf(rec[2], q.rc_z[0], q.rc_z[1]);
+    const float m_z = __builtin_fmaf(kz, q.rc_z[0], q.rc_z[1]);
     const f32x2 near_xy = __builtin_elementwise_fma(hh, q.na_xy, m_xy);
     const f32x2 far_xy = __builtin_elementwise_fma(hh, -q.na_xy, m_xy);
     const f32x2 nf_z = __builtin_elementwise_fma(hh, q.a_z_pm, f32x2{m_z, m_z});
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(near_xy[0], near_xy[1]), nf_z[0]);
-    const float hi = __builtin_fminf(__builtin_fminf(far_xy[0], far_xy[1]), nf_z[1]);
-    return !(lo - hi > q.tol);
+    lo = __builtin_fmaxf(__builtin_fmaxf(near_xy[0], near_xy[1]), nf_z[0]);
+    hi = __builtin_fminf(__builtin_fminf(far_xy[0], far_xy[1]), nf_z[1]);
 }
 
 // reference src/cube.rs:90-145 (slab test and distance), src/lib.rs:29-35 (minmax)
@@ -267,9 +288,11 @@ struct Hit {
 
 // reference src/cube.rs:146-204, evaluated for the winning cube only (the reference evaluates it for
 // every slab-passing candidate and throws the losers away)
-DEV Hit cube_resolve(const Params& P, uint32_t idx, float distance, V3 o, V3 d)
+DEV Hit cube_resolve(const Params& P, uint32_t idx, V3 o, V3 d)
 {
     const CubeRec c = P.cubes[idx];  // per-lane gather: lanes may have different winners
+    float distance = 0.0f;
+    (void)cube_exact(c, o, d, distance);  // the winner's reference distance (cube.rs:90-145), once per ray
     Hit h;
     h.p = vadd(o, vscale(d, distance));
     h.n = v3(0.0f, 0.0f, 0.0f);
@@ -302,9 +325,11 @@ DEV Hit cube_resolve(const Params& P, uint32_t idx, float distance, V3 o, V3 d)
 }
 
 // reference src/sphere.rs:39-49
-DEV Hit sphere_resolve(const Params& P, uint32_t idx, float distance, V3 o, V3 d)
+DEV Hit sphere_resolve(const Params& P, uint32_t idx, V3 o, V3 d)
 {
     const SphereRec s = P.spheres[idx];
+    float distance = 0.0f;
+    (void)sphere_exact(s, o, d, distance);
     const SphereMeta m = P.sphere_meta[idx];
     Hit h;
     h.p = vadd(o, vscale(d, distance));
@@ -367,140 +392,278 @@ DEV V3 refract(V3 i, V3 n, float eta_t)
 // closely than the 1-2 ulp f32 device routine.  Two calls per shaded hit: not a hot spot.
 DEV float powf_like_libm(float x, float y) { return (float)pow((double)x, (double)y); }
 
-// ---------------------------------------------------------------- nearest hit (render.rs:87-101)
-template <int PASS, bool COUNT>
-DEV void nearest_query(const Params& P, V3 o, V3 d, uint32_t& best_idx, float& best_dist, Counters& cnt)
+// ---------------------------------------------------------------- wave-level helpers
+// Everything from here on runs with all 64 lanes enabled: control flow depends only on wave-uniform
+// conditions (ballots), per-lane state is carried in predicates (`active`, `hit`, `done`).  That is
+// what lets one wave cull the cube list cooperatively (lane j examines cube base+j).
+DEV unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+DEV bool wave_any(bool p) { return wave_ballot(p) != 0ull; }
+
+template <int CTRL, int ROW_MASK>
+DEV float dpp_f(float old, float v)
 {
-    best_idx = kNoHit;
-    best_dist = __builtin_inff();
-    if constexpr (PASS == PASS_CUBES) {
-        const RayPre q = ray_pre(P, o, d);
-        const uint32_t n = P.n_cubes;
-        // 4 filter records (one 64-byte line, one s_load_dwordx16) per iteration; the array is padded
-        // to a multiple of 4 with far-away zero-size boxes.  One branch per batch: the exact path
-        // runs only when some lane's filter could not prove a miss.
-        f32x16 cur = load_filt4_uniform(P.cube_filt, 0u);
-        for (uint32_t base = 0; base < n; base += 4u) {
-            const uint32_t nb = base + 4u;
-            const f32x16 nxt = load_filt4_uniform(P.cube_filt, nb < n ? nb : base);  // prefetch
-            const bool c0 = cube_filter(f32x4{cur[0], cur[1], cur[2], cur[3]}, q);
-            const bool c1 = cube_filter(f32x4{cur[4], cur[5], cur[6], cur[7]}, q);
-            const bool c2 = cube_filter(f32x4{cur[8], cur[9], cur[10], cur[11]}, q);
-            const bool c3 = cube_filter(f32x4{cur[12], cur[13], cur[14], cur[15]}, q);
-            if (c0 | c1 | c2 | c3) {
-                const bool cand[4] = {c0, c1, c2, c3};
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const uint32_t i = base + k;
-                    if (i < n && cand[k]) {
-                        const CubeRec c = load_cube_uniform(P.cubes, i);
-                        float dist;
-                        if (cube_exact(c, o, d, dist)) {
-                            if (dist < best_dist) {  // strict <: lowest index wins ties, NaN never wins
-                                best_dist = dist;
-                                best_idx = i;
-                            }
-                        }
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
+DEV float readlane_f(float v, uint32_t lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)lane));
+}
+// max over the 64 lanes (all enabled), result wave-uniform.  6 DPP-modified v_max_f32: an inclusive
+// scan inside each row of 16 (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals
+// into lane 63.
+DEV float wave_max(float v)
+{
+    const float id = -__builtin_inff();
+    v = __builtin_fmaxf(v, dpp_f<0x111, 0xf>(id, v));
+    v = __builtin_fmaxf(v, dpp_f<0x112, 0xf>(id, v));
+    v = __builtin_fmaxf(v, dpp_f<0x114, 0xf>(id, v));
+    v = __builtin_fmaxf(v, dpp_f<0x118, 0xf>(id, v));
+    v = __builtin_fmaxf(v, dpp_f<0x142, 0xa>(id, v));
+    v = __builtin_fmaxf(v, dpp_f<0x143, 0xc>(id, v));
+    return readlane_f(v, 63u);
+}
+
+// ---------------------------------------------------------------- wave-cooperative cull
+// A line o + t d misses the box (centre k, half size h) iff one of the three coordinate-plane
+// separating-axis tests holds:  |(k_i-o_i) d_j - (k_j-o_j) d_i| > h (|d_i| + |d_j|)   (i,j) = xy, yz, zx.
+// (This is the slab test of cube.rs:90-113 with the divisions multiplied out.)  With the line moment
+// W_ij = o_i d_j - o_j d_i the left side is k_i d_j - k_j d_i - W_ij: linear in the cube centre with
+// per-ray coefficients.  For a WAVE of rays, d and W are bounded by centre +- radius over the active
+// lanes, which gives one conservative test per cube for all 64 rays; lane j evaluates it for cube
+// base+j and a ballot turns the answers into a 64-bit candidate mask.
+struct CullPre {  // wave-uniform
+    float dxc, dyc, dzc, dxr, dyr, dzr;        // direction: centre, radius
+    float wxyc, wyzc, wzxc, wxyr, wyzr, wzxr;  // moment: centre, radius (+ rounding slack)
+    float sxy, syz, szx;                       // upper bounds of |d_i| + |d_j|
+    bool all;                                  // some active ray is non-finite or huge: keep every cube
+};
+
+DEV CullPre cull_pre(const Params& P, bool active, V3 o, V3 d, bool wild)
+{
+    CullPre c;
+    const unsigned long long am = wave_ballot(active);
+    const uint32_t ref = am ? (uint32_t)__builtin_ctzll(am) : 0u;
+    c.all = wave_any(active && wild);
+    const float wxy = o.x * d.y - o.y * d.x, wyz = o.y * d.z - o.z * d.y, wzx = o.z * d.x - o.x * d.z;
+    c.dxc = readlane_f(d.x, ref); c.dyc = readlane_f(d.y, ref); c.dzc = readlane_f(d.z, ref);
+    c.wxyc = readlane_f(wxy, ref); c.wyzc = readlane_f(wyz, ref); c.wzxc = readlane_f(wzx, ref);
+    const float z = 0.0f;
+    c.dxr = wave_max(active ? __builtin_fabsf(d.x - c.dxc) : z);
+    c.dyr = wave_max(active ? __builtin_fabsf(d.y - c.dyc) : z);
+    c.dzr = wave_max(active ? __builtin_fabsf(d.z - c.dzc) : z);
+    const float wxyr = wave_max(active ? __builtin_fabsf(wxy - c.wxyc) : z);
+    const float wyzr = wave_max(active ? __builtin_fabsf(wyz - c.wyzc) : z);
+    const float wzxr = wave_max(active ? __builtin_fabsf(wzx - c.wzxc) : z);
+    const float omax = wave_max(active ? __builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fmaxf(__builtin_fabsf(o.y), __builtin_fabsf(o.z))) : z);
+    const float ax = __builtin_fabsf(c.dxc) + c.dxr, ay = __builtin_fabsf(c.dyc) + c.dyr, az = __builtin_fabsf(c.dzc) + c.dzr;
+    c.sxy = ax + ay; c.syz = ay + az; c.szx = az + ax;
+    // Rounding slack.  Sources (u = 2^-24, B = largest bound magnitude, O = omax, D = ax+ay+az >= |d_c|):
+    //   this test's own fma chains and the per-lane moments      <= ~12 u (B + O) D
+    //   the reference's rounded t values vs exact arithmetic      <= ~12 u (B + O) D   (see cube_slab_approx)
+    // 2^-17 (B + O + 1) max(D, 1) = 128 u (...) covers both several times over.
+    const float slack = 0x1p-17f * (P.bound_max + omax + 1.0f) * __builtin_fmaxf(ax + ay + az, 1.0f);
+    c.wxyr = wxyr + slack; c.wyzr = wyzr + slack; c.wzxr = wzxr + slack;
+    return c;
+}
+
+// lane-private cube (kx,ky,kz,h): true -> some active ray of the wave may pass the slab test
+DEV bool cull_test(f32x4 k, const CullPre& c)
+{
+    const float gxy = __builtin_fmaf(k[0], c.dyc, __builtin_fmaf(-k[1], c.dxc, -c.wxyc));
+    const float lxy = __builtin_fmaf(k[3], c.sxy, __builtin_fmaf(__builtin_fabsf(k[0]), c.dyr, __builtin_fmaf(__builtin_fabsf(k[1]), c.dxr, c.wxyr)));
+    const float gyz = __builtin_fmaf(k[1], c.dzc, __builtin_fmaf(-k[2], c.dyc, -c.wyzc));
+    const float lyz = __builtin_fmaf(k[3], c.syz, __builtin_fmaf(__builtin_fabsf(k[1]), c.dzr, __builtin_fmaf(__builtin_fabsf(k[2]), c.dyr, c.wyzr)));
+    const float gzx = __builtin_fmaf(k[2], c.dxc, __builtin_fmaf(-k[0], c.dzc, -c.wzxc));
+    const float lzx = __builtin_fmaf(k[3], c.szx, __builtin_fmaf(__builtin_fabsf(k[2]), c.dxr, __builtin_fmaf(__builtin_fabsf(k[0]), c.dzr, c.wzxr)));
+    const bool sep = (__builtin_fabsf(gxy) > lxy) || (__builtin_fabsf(gyz) > lyz) || (__builtin_fabsf(gzx) > lzx);
+    return c.all || !sep;  // NaN compares false -> candidate
+}
+
+// ---------------------------------------------------------------- cube queries
+enum { Q_NEAREST = 0, Q_NEAREST_EXACT = 1, Q_SHADOW = 2 };
+
+struct QState {
+    float b1, b2;       // Q_NEAREST: the two smallest approximate distances ...
+    uint32_t i1;        //            ... and the cube index of the smallest
+    float best;         // Q_NEAREST_EXACT: the reference's fold (render.rs:94-101) on exact distances
+    uint32_t best_i;
+    bool done;          // Q_SHADOW: first cube in array order whose exact test passes
+    uint32_t blocker;
+    float tol;          // the ray's 2E (out)
+};
+
+// One pass over the cube list for the whole wave.
+//   Q_NEAREST        approximate distances with error bound E for every cube the two-sided filter
+//                    proves to pass; cubes it can neither prove nor refute are evaluated exactly on the
+//                    spot (rare).  The caller decides the winner from (b1, b2, i1) and falls back to
+//                    Q_NEAREST_EXACT for lanes where b2 - b1 <= 2E ("contested": duplicates, ties).
+//   Q_NEAREST_EXACT  exact evaluation of every candidate for the lanes in `active`.
+//   Q_SHADOW         render.rs:44-70 list-order semantics, exclusion by id (render.rs:113).
+template <int MODE>
+DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st)
+{
+    const uint32_t n = P.n_cubes;
+    if (n == 0u) return;
+    const RayPre q = ray_pre(P, o, d);
+    st.tol = q.tol;
+    const CullPre cp = cull_pre(P, active, o, d, q.wild);
+    const uint32_t lane = threadIdx.x & 63u;
+    const f32x4* filt = (const f32x4*)P.cube_filt;
+    f32x4 rec = filt[lane];
+    bool all_done = false;
+    for (uint32_t base = 0; base < n && !all_done; base += 64u) {
+        const uint32_t nb = base + 64u;
+        const f32x4 nxt = filt[(nb < n ? nb : base) + lane];  // prefetch (array is padded to a multiple of 64)
+        uint32_t ids = 0u;
+        if constexpr (MODE == Q_SHADOW) ids = P.cube_id[base + lane];
+        unsigned long long M = wave_ballot(cull_test(rec, cp) && (base + lane < n));
+        while (M != 0ull) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(M);
+            M &= M - 1ull;
+            const uint32_t i = base + b;
+            const float kx = readlane_f(rec[0], b), ky = readlane_f(rec[1], b), kz = readlane_f(rec[2], b), kh = readlane_f(rec[3], b);
+            float lo, hi;
+            cube_slab_approx(kx, ky, kz, kh, q, lo, hi);
+            const float gap = lo - hi;
+            bool live = active && !(gap > q.tol);  // not proven to miss
+            if constexpr (MODE == Q_SHADOW) {
+                const uint32_t cid = (uint32_t)__builtin_amdgcn_readlane((int)ids, (int)b);
+                live = live && !st.done && (cid != impact_id);
+            }
+            bool sure = gap < -q.tol;  // proven to pass
+            if constexpr (MODE == Q_NEAREST) sure = sure && (__builtin_fabsf(lo) > q.err);  // and the sign of tmin is certain
+            if constexpr (MODE == Q_NEAREST_EXACT) sure = false;
+            const bool amb = live && !sure;
+            float dist = (lo < 0.0f) ? hi : lo;  // cube.rs:145 on the approximate interval
+            if (wave_any(amb)) {
+                if (amb) {
+                    const CubeRec c = load_cube_uniform(P.cubes, i);
+                    float ed;
+                    const bool pass = cube_exact(c, o, d, ed);
+                    live = pass && (ed == ed);  // a NaN distance is Some but never wins (render.rs:95)
+                    if constexpr (MODE == Q_SHADOW) live = pass;
+                    dist = ed;
+                }
+            }
+            if constexpr (MODE == Q_NEAREST) {
+                const bool first = live && (dist < st.b1);
+                const float nb2 = first ? st.b1 : __builtin_fminf(st.b2, dist);
+                st.b2 = live ? nb2 : st.b2;
+                st.b1 = first ? dist : st.b1;
+                st.i1 = first ? i : st.i1;
+            } else if constexpr (MODE == Q_NEAREST_EXACT) {
+                const bool win = live && (dist < st.best);  // strict <: lowest index wins ties
+                st.best = win ? dist : st.best;
+                st.best_i = win ? i : st.best_i;
+            } else {
+                if (wave_any(live)) {
+                    st.blocker = live ? i : st.blocker;
+                    st.done = st.done || live;
+                    if (!wave_any(active && !st.done)) {
+                        all_done = true;
+                        M = 0ull;
                     }
                 }
             }
-            cur = nxt;
         }
-        if constexpr (COUNT) cnt.cube_tests += n;
+        rec = nxt;
+    }
+}
+
+// ---------------------------------------------------------------- nearest hit (render.rs:87-101)
+template <int PASS, bool COUNT>
+DEV uint32_t nearest_query(const Params& P, bool active, V3 o, V3 d, Counters& cnt)
+{
+    uint32_t best_idx = kNoHit;
+    if constexpr (PASS == PASS_CUBES) {
+        QState st;
+        st.b1 = __builtin_inff(); st.b2 = __builtin_inff(); st.i1 = kNoHit;
+        st.best = __builtin_inff(); st.best_i = kNoHit; st.done = false; st.blocker = kNoHit; st.tol = 0.0f;
+        cube_query<Q_NEAREST>(P, active, o, d, 0u, st);
+        best_idx = active ? st.i1 : kNoHit;
+        // contested: a second candidate within 2E of the best (exact duplicates, shared edges).  NaN -> contested.
+        const bool contested = active && (st.i1 != kNoHit) && !(st.b2 - st.b1 > st.tol);
+        if (wave_any(contested)) {
+            cube_query<Q_NEAREST_EXACT>(P, contested, o, d, 0u, st);
+            best_idx = contested ? st.best_i : best_idx;
+        }
+        if constexpr (COUNT) cnt.cube_tests += active ? P.n_cubes : 0u;
     } else {
         const uint32_t n = P.n_spheres;
+        float best_dist = __builtin_inff();
         for (uint32_t i = 0; i < n; ++i) {
             const SphereRec s = load_sphere_uniform(P.spheres, i);
-            float dist;
-            if (sphere_exact(s, o, d, dist)) {
-                if (dist < best_dist) {
-                    best_dist = dist;
-                    best_idx = i;
-                }
-            }
+            float dist = 0.0f;
+            const bool win = sphere_exact(s, o, d, dist) && active && (dist < best_dist);
+            best_dist = win ? dist : best_dist;
+            best_idx = win ? i : best_idx;
         }
-        if constexpr (COUNT) cnt.sphere_tests += n;
+        if constexpr (COUNT) cnt.sphere_tests += active ? n : 0u;
     }
-    if constexpr (COUNT) cnt.nearest_rays += 1;
+    if constexpr (COUNT) cnt.nearest_rays += active ? 1u : 0u;
+    return best_idx;
 }
 
 // ---------------------------------------------------------------- shadow (render.rs:44-70)
 // First object in array order, among those whose id differs from the impact object's
 // (render.rs:113), whose ray_intersect returns Some.  Not the nearest one.
 template <int PASS, bool COUNT>
-DEV float shadow_query(const Params& P, V3 origin, V3 light_pos, uint32_t impact_id, uint32_t& blocker, Counters& cnt)
+DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, uint32_t impact_id, uint32_t& blocker, Counters& cnt)
 {
     const V3 dir = vnormalize(vsub(light_pos, origin));
     blocker = kNoHit;
     float sdist = 0.0f;
-    bool done = false;
-    if constexpr (COUNT) cnt.shadow_rays += 1;
+    if constexpr (COUNT) cnt.shadow_rays += active ? 1u : 0u;
     if constexpr (PASS == PASS_CUBES) {
-        const RayPre q = ray_pre(P, origin, dir);
-        const uint32_t n = P.n_cubes;
-        // Same batched filter as nearest_query.  The id exclusion (render.rs:113) is applied in the
-        // rare exact path only: excluded cubes that the filter happens to pass cost one compare.
-        f32x16 cur = load_filt4_uniform(P.cube_filt, 0u);
-        for (uint32_t base = 0; base < n; base += 4u) {
-            const uint32_t nb = base + 4u;
-            const f32x16 nxt = load_filt4_uniform(P.cube_filt, nb < n ? nb : base);
-            const bool c0 = !done && cube_filter(f32x4{cur[0], cur[1], cur[2], cur[3]}, q);
-            const bool c1 = !done && cube_filter(f32x4{cur[4], cur[5], cur[6], cur[7]}, q);
-            const bool c2 = !done && cube_filter(f32x4{cur[8], cur[9], cur[10], cur[11]}, q);
-            const bool c3 = !done && cube_filter(f32x4{cur[12], cur[13], cur[14], cur[15]}, q);
-            if (c0 | c1 | c2 | c3) {
-                const bool cand[4] = {c0, c1, c2, c3};
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const uint32_t i = base + k;
-                    if (i < n && cand[k] && !done) {
-                        const CubeRec c = load_cube_uniform(P.cubes, i);
-                        float dist;
-                        if (c.id != impact_id && cube_exact(c, origin, dir, dist)) {
-                            done = true;
-                            blocker = i;
-                            sdist = dist;
-                        }
-                    }
-                }
-                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-            }
-            cur = nxt;
+        QState st;
+        st.b1 = 0.0f; st.b2 = 0.0f; st.i1 = kNoHit; st.best = 0.0f; st.best_i = kNoHit;
+        st.done = false; st.blocker = kNoHit; st.tol = 0.0f;
+        cube_query<Q_SHADOW>(P, active, origin, dir, impact_id, st);
+        blocker = (active && st.done) ? st.blocker : kNoHit;
+        if (wave_any(blocker != kNoHit)) {
+            // the blocker's exact distance (per-lane gather; the loop only proved that it passes)
+            const CubeRec c = P.cubes[blocker != kNoHit ? blocker : 0u];
+            float ed = 0.0f;
+            (void)cube_exact(c, origin, dir, ed);
+            sdist = ed;
         }
         if constexpr (COUNT) {
-            // executed tests = cubes before (and including) the blocker whose id differs from the impact id
-            const uint32_t limit = done ? blocker + 1u : n;
+            // executed tests = cubes up to and including the blocker whose id differs from the impact id
+            const uint32_t n = P.n_cubes;
+            const uint32_t limit = (blocker != kNoHit) ? blocker + 1u : n;
             for (uint32_t i = 0; i < n; ++i) {
                 const uint32_t id = load_cube_uniform(P.cubes, i).id;
-                cnt.cube_tests += (i < limit && id != impact_id) ? 1u : 0u;
+                cnt.cube_tests += (active && i < limit && id != impact_id) ? 1u : 0u;
             }
         }
     } else {
         const uint32_t n = P.n_spheres;
+        bool done = false;
         for (uint32_t i = 0; i < n; ++i) {
             const SphereRec s = load_sphere_uniform(P.spheres, i);
-            const bool tested = !done && (load_sphere_meta_uniform(P.sphere_meta, i).id != impact_id);
+            const bool tested = active && !done && (load_sphere_meta_uniform(P.sphere_meta, i).id != impact_id);
             if constexpr (COUNT) cnt.sphere_tests += tested ? 1u : 0u;
-            if (tested) {
-                float dist;
-                if (sphere_exact(s, origin, dir, dist)) {
-                    done = true;
-                    blocker = i;
-                    sdist = dist;
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+            float dist = 0.0f;
+            const bool pass = sphere_exact(s, origin, dir, dist) && tested;
+            blocker = pass ? i : blocker;
+            sdist = pass ? dist : sdist;
+            done = done || pass;
+            if (!wave_any(active && !done)) break;
         }
     }
     float shadow = 0.0f;
-    if (blocker != kNoHit && !(sdist < 0.0f)) {  // render.rs:56-58: negative distance -> 0
+    if (wave_any(blocker != kNoHit)) {
+        const bool has = (blocker != kNoHit) && !(sdist < 0.0f);  // render.rs:56-58: negative distance -> 0
+        const uint32_t bi = (blocker != kNoHit) ? blocker : 0u;
         const V3 sp = vadd(origin, vscale(dir, sdist));
         const V3 dv = vsub(sp, light_pos);  // distance2(a,b) = norm_squared(b-a)
         const float d2 = vdot(dv, dv);
         uint32_t bm;
-        if constexpr (PASS == PASS_CUBES) bm = P.cube_mat[blocker];
-        else bm = P.sphere_meta[blocker].material;
-        shadow = sdist / d2 * (1.0f - P.mats[bm].transparency);
+        if constexpr (PASS == PASS_CUBES) bm = P.cube_mat[bi];
+        else bm = P.sphere_meta[bi].material;
+        const float sh = sdist / d2 * (1.0f - P.mats[bm].transparency);
+        shadow = has ? sh : 0.0f;
     }
     return shadow;
 }
@@ -511,31 +674,32 @@ DEV float shadow_query(const Params& P, V3 origin, V3 light_pos, uint32_t impact
 // non-negative u8 and `+` saturates, ((acc + X) + Y) + Z == min(255, acc+X+Y+Z), so the fold
 // equals min(255, sum_l DS_l + L*(refl*k_r) + L*(refr*k_t)) per channel and can be evaluated
 // after the children return.
+//
+// Predicated form: every lane of the wave executes the call; `active` says whether the lane has a
+// ray.  Results of inactive lanes are unspecified and unused.
 template <int PASS, int DEPTH, bool DBG, bool COUNT>
-DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uint32_t& hit_idx, Totals& tot)
+DEV Col cast_ray(const Params& P, bool active, V3 o, V3 d, float ambient, uint32_t& hash, uint32_t& hit_idx, Totals& tot)
 {
     const Col sky = col_from_hex(P.sky);
     hit_idx = kNoHit;
+    hash = kHashCut;
     if constexpr (DEPTH > 3) {
-        hash = kHashCut;
         return sky;
     } else {
-        if ((uint32_t)DEPTH > P.max_depth) {  // wave-uniform
-            hash = kHashCut;
-            return sky;
-        }
-        uint32_t idx;
-        float dist;
+        if ((uint32_t)DEPTH > P.max_depth) return sky;  // wave-uniform
+        if (!wave_any(active)) return sky;                // wave-uniform
         Counters cnt = {0u, 0u, 0u, 0u, 0u};
-        nearest_query<PASS, COUNT>(P, o, d, idx, dist, cnt);
+        const uint32_t idx = nearest_query<PASS, COUNT>(P, active, o, d, cnt);
         hit_idx = idx;
         uint32_t h = hmix(kHashBasis, idx);
         Col result = sky;
-        if (idx != kNoHit) {
-            if constexpr (COUNT) cnt.shaded_hits += 1;
+        const bool hit_any = active && (idx != kNoHit);
+        if (wave_any(hit_any)) {
+            const uint32_t sidx = hit_any ? idx : 0u;  // lanes without a hit shade object 0 and discard the result
+            if constexpr (COUNT) cnt.shaded_hits += hit_any ? 1u : 0u;
             Hit hit;
-            if constexpr (PASS == PASS_CUBES) hit = cube_resolve(P, idx, dist, o, d);
-            else hit = sphere_resolve(P, idx, dist, o, d);
+            if constexpr (PASS == PASS_CUBES) hit = cube_resolve(P, sidx, o, d);
+            else hit = sphere_resolve(P, sidx, o, d);
             const MatRec m = P.mats[hit.material];
 
             Col tx;
@@ -553,8 +717,8 @@ DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uin
                 const V3 light_dir = vnormalize(vsub(lp, hit.p));
                 const V3 reflect_dir = vnormalize(reflect(vneg(light_dir), hit.n));
                 uint32_t blocker;
-                const float shadow = shadow_query<PASS, COUNT>(P, hit.p, lp, hit.id, blocker, cnt);
-                if constexpr (DBG) h = hmix(h, blocker);
+                const float shadow = shadow_query<PASS, COUNT>(P, hit_any, hit.p, lp, hit.id, blocker, cnt);
+                if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
                 const float light_intensity = L.intensity * (1.0f - shadow);
                 const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
                 const Col diffuse = col_mul(col_mul(tx_a, diffuse_intensity), light_intensity);
@@ -564,11 +728,11 @@ DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uin
             }
 
             // children (render.rs:154-193)
-            const bool has_refl = m.reflectivity > 0.0f;
-            const bool has_refr = m.transparency > 0.0f;
+            const bool has_refl = hit_any && (m.reflectivity > 0.0f);
+            const bool has_refr = hit_any && (m.transparency > 0.0f);
             Col c_refl = Col{0.0f, 0.0f, 0.0f}, c_refr = Col{0.0f, 0.0f, 0.0f};
             uint32_t h_refl = 0u, h_refr = 0u;
-            if (has_refl || has_refr) {
+            if (wave_any(has_refl || has_refr)) {
                 const V3 refl_d = vnormalize(reflect(vneg(d), hit.n));
                 const V3 refl_o = vadd(hit.p, vscale(hit.n, 1e-2f));
                 const V3 refr_d = refract(d, hit.n, m.ior);
@@ -577,26 +741,30 @@ DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uin
                 // slot 0 = the lane's first pending child, slot 1 = its second: lanes whose only
                 // child is a refraction trace it together with other lanes' reflections.
                 for (int slot = 0; slot < 2; ++slot) {
-                    if (slot < n_child) {
-                        const bool is_refl = (slot == 0) && has_refl;
-                        const V3 co = is_refl ? refl_o : refr_o;
-                        const V3 cd = is_refl ? refl_d : refr_d;
-                        uint32_t ch, cidx;
-                        const Col cc = cast_ray<PASS, DEPTH + 1, DBG, COUNT>(P, co, cd, ambient, ch, cidx, tot);
-                        if (is_refl) { c_refl = cc; h_refl = ch; }
-                        else { c_refr = cc; h_refr = ch; }
-                    }
+                    const bool child = slot < n_child;
+                    if (!wave_any(child)) break;
+                    const bool is_refl = (slot == 0) && has_refl;
+                    const V3 co = is_refl ? refl_o : refr_o;
+                    const V3 cd = is_refl ? refl_d : refr_d;
+                    uint32_t ch, cidx;
+                    const Col cc = cast_ray<PASS, DEPTH + 1, DBG, COUNT>(P, child, co, cd, ambient, ch, cidx, tot);
+                    if (child && is_refl) { c_refl = cc; h_refl = ch; }
+                    if (child && !is_refl) { c_refr = cc; h_refr = ch; }
                 }
             }
             const Col rl = col_mul(c_refl, m.reflectivity);
             const Col rr = col_mul(c_refr, m.transparency);
             const float fl = (float)nl;
-            result.r = __builtin_fminf(sum.r + fl * rl.r + fl * rr.r, 255.0f);
-            result.g = __builtin_fminf(sum.g + fl * rl.g + fl * rr.g, 255.0f);
-            result.b = __builtin_fminf(sum.b + fl * rl.b + fl * rr.b, 255.0f);
+            Col lit;
+            lit.r = __builtin_fminf(sum.r + fl * rl.r + fl * rr.r, 255.0f);
+            lit.g = __builtin_fminf(sum.g + fl * rl.g + fl * rr.g, 255.0f);
+            lit.b = __builtin_fminf(sum.b + fl * rl.b + fl * rr.b, 255.0f);
+            result.r = hit_any ? lit.r : sky.r;
+            result.g = hit_any ? lit.g : sky.g;
+            result.b = hit_any ? lit.b : sky.b;
             if constexpr (DBG) {
-                h = hmix(h, h_refl);
-                h = hmix(h, h_refr);
+                const uint32_t hh = hmix(hmix(h, h_refl), h_refr);
+                h = hit_any ? hh : h;
             }
         }
         if constexpr (COUNT) {
@@ -611,10 +779,13 @@ DEV Col cast_ray(const Params& P, V3 o, V3 d, float ambient, uint32_t& hash, uin
 }
 
 // ---------------------------------------------------------------- render (render.rs:234-324)
-// One lane per pixel; a wave covers an 8x8 pixel tile (coherent rays -> few divergent exact tests),
-// a 256-thread workgroup covers 16x16 pixels.
+// One lane per pixel; a wave covers an 8x8 pixel tile (coherent rays -> tight wave-level bounds in
+// the cull), a 256-thread workgroup covers 16x16 pixels.
+#ifndef RTX_MIN_WAVES
+#define RTX_MIN_WAVES 4
+#endif
 template <bool DBG, bool COUNT>
-__global__ __launch_bounds__(256) void render_kernel(const Params P)
+__global__ __launch_bounds__(256, RTX_MIN_WAVES) void render_kernel(const Params P)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -626,28 +797,30 @@ __global__ __launch_bounds__(256) void render_kernel(const Params P)
     Totals cnt;
 #pragma unroll
     for (int k = 0; k < 10; ++k) cnt.v[k] = 0ull;
-    if (x < P.width && y < P.y1) {
-        const float width = (float)P.width, height = (float)P.height;
-        const float aspect = width / height;
-        float sx = (2.0f * (float)x) / width - 1.0f;
-        const float sy = -(2.0f * (float)y) / height + 1.0f;
-        sx = sx * aspect;
-        const V3 v = vnormalize(v3(sx, sy, -1.0f));
-        // camera.rs:38-40: v.x*right + v.y*up - v.z*forward, normalised
-        const V3 right = v3(P.right[0], P.right[1], P.right[2]);
-        const V3 up = v3(P.up[0], P.up[1], P.up[2]);
-        const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
-        const V3 dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));
-        const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
+    const bool active = (x < P.width) && (y < P.y1);  // lanes outside the frame stay in the wave, inactive
 
-        uint32_t hs, hc, hit_s, hit_c;
-        const Col cs = cast_ray<PASS_SPHERES, 0, DBG, COUNT>(P, eye, dir, 1.0f, hs, hit_s, cnt);
-        const Col cc = cast_ray<PASS_CUBES, 0, DBG, COUNT>(P, eye, dir, P.ambient, hc, hit_c, cnt);
-        const uint32_t s_hex = col_to_hex(cs);
-        uint32_t px = (s_hex == P.sky) ? col_to_hex(cc) : s_hex;  // render.rs:308-312
-        const size_t i_frame = (size_t)y * P.width + x;
-        if (i_frame == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
-        const size_t i_band = (size_t)out_row * P.width + x;
+    const float width = (float)P.width, height = (float)P.height;
+    const float aspect = width / height;
+    float sx = (2.0f * (float)x) / width - 1.0f;
+    const float sy = -(2.0f * (float)y) / height + 1.0f;
+    sx = sx * aspect;
+    const V3 v = vnormalize(v3(sx, sy, -1.0f));
+    // camera.rs:38-40: v.x*right + v.y*up - v.z*forward, normalised
+    const V3 right = v3(P.right[0], P.right[1], P.right[2]);
+    const V3 up = v3(P.up[0], P.up[1], P.up[2]);
+    const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
+    const V3 dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));
+    const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
+
+    uint32_t hs, hc, hit_s, hit_c;
+    const Col cs = cast_ray<PASS_SPHERES, 0, DBG, COUNT>(P, active, eye, dir, 1.0f, hs, hit_s, cnt);
+    const Col cc = cast_ray<PASS_CUBES, 0, DBG, COUNT>(P, active, eye, dir, P.ambient, hc, hit_c, cnt);
+    const uint32_t s_hex = col_to_hex(cs);
+    uint32_t px = (s_hex == P.sky) ? col_to_hex(cc) : s_hex;  // render.rs:308-312
+    const size_t i_frame = (size_t)y * P.width + x;
+    if (i_frame == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
+    const size_t i_band = (size_t)out_row * P.width + x;
+    if (active) {
         if constexpr (!COUNT) {
             if (P.out) P.out[i_band] = px;
         }
