@@ -157,8 +157,9 @@ DEV void totals_add(Totals& t, const Counters& c, unsigned long long w)
 // Error bound, u = 2^-24, no overflow/underflow (dir_ok/org_ok/fast_ok guarantee the ranges):
 //   reference  t = RN(RN(RN(k -+ h) - o)/d)            |t  - T| <= 3u (B+|o|)|r| (1+O(u)),  T exact
 //   filter     t~ = RN(fma(h,-+a, RN(fma(k,r,-RN(o r)))))  |t~ - T| <= 5u (B+|o|)|r| (1+O(u))
+//              with r = v_rcp_f32(d), 1 ulp = 2u relative                +2u (B+|o|)|r|
 // with B >= |k|+h the largest bound magnitude in the scene.  lo = max3 and hi = min3 each move by at
-// most the largest per-axis error E = 8u max_c (B+|o_c|)|r_c|, so lo~ - hi~ > 2E implies lo > hi, which
+// most the largest per-axis error E = 10u max_c (B+|o_c|)|r_c|, so lo~ - hi~ > 2E implies lo > hi, which
 // is exactly when the reference's staged slab test (cube.rs:101,113) returns None.  tol = 32u max_c(...)
 // = 2E: twice the requirement.  Rays outside the safe ranges get tol = +inf (every cube is a
 // candidate), and the negated compare makes NaN a candidate too.
@@ -187,7 +188,8 @@ DEV RayPre ray_pre(const Params& P, V3 o, V3 d)
 {
     RayPre q;
     const bool safe = (P.fast_ok != 0u) && dir_ok(d.x) && dir_ok(d.y) && dir_ok(d.z) && org_ok(o.x) && org_ok(o.y) && org_ok(o.z);
-    const float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;
+    // v_rcp_f32: 1 ulp (2u relative) instead of the correctly rounded quotient; the bound below budgets for it
+    const float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
     const float ax = __builtin_fabsf(rx), ay = __builtin_fabsf(ry), az = __builtin_fabsf(rz);
     q.r_xy = f32x2{rx, ry};
     q.c_xy = f32x2{-(o.x * rx), -(o.y * ry)};
@@ -390,7 +392,20 @@ DEV V3 refract(V3 i, V3 n, float eta_t)
 // f32::powf.  The reference calls glibc powf (error < 1 ulp, correctly rounded in all but a
 // vanishing fraction of cases); evaluating in f64 and rounding once reproduces that far more
 // closely than the 1-2 ulp f32 device routine.  Two calls per shaded hit: not a hot spot.
-DEV float powf_like_libm(float x, float y) { return (float)pow((double)x, (double)y); }
+DEV float powf_like_libm(float x, float y)
+{
+    // exact special cases of powf first (most shaded points have a clamped base of exactly 0):
+    //   powf(+0, y>0) = +0, powf(1, y) = 1, powf(x, 1) = x (also for NaN x)
+    const bool zero = (x == 0.0f) && (y > 0.0f);
+    const bool one = (x == 1.0f);
+    const bool ident = (y == 1.0f);
+    float r = zero ? 0.0f : (one ? 1.0f : x);
+    const bool full = !(zero || one || ident);
+    if (__builtin_amdgcn_ballot_w64(full) != 0ull) {
+        if (full) r = (float)pow((double)x, (double)y);
+    }
+    return r;
+}
 
 // ---------------------------------------------------------------- wave-level helpers
 // Everything from here on runs with all 64 lanes enabled: control flow depends only on wave-uniform
@@ -433,10 +448,12 @@ DEV float wave_max(float v)
 // lanes, which gives one conservative test per cube for all 64 rays; lane j evaluates it for cube
 // base+j and a ballot turns the answers into a 64-bit candidate mask.
 struct CullPre {  // wave-uniform
-    float dxc, dyc, dzc, dxr, dyr, dzr;        // direction: centre, radius
-    float wxyc, wyzc, wzxc, wxyr, wyzr, wzxr;  // moment: centre, radius (+ rounding slack)
-    float sxy, syz, szx;                       // upper bounds of |d_i| + |d_j|
-    bool all;                                  // some active ray is non-finite or huge: keep every cube
+    float dxc, dyc, dzc;        // direction of the reference lane
+    float wxyc, wyzc, wzxc;     // its moment
+    float dr;                   // max over active lanes and axes of |d - dc|
+    float wr;                   // same for the moment, plus rounding slack
+    float sxy, syz, szx;        // upper bounds of |d_i| + |d_j|
+    bool all;                   // some active ray is non-finite or huge: keep every cube
 };
 
 DEV CullPre cull_pre(const Params& P, bool active, V3 o, V3 d, bool wild)
@@ -449,33 +466,34 @@ DEV CullPre cull_pre(const Params& P, bool active, V3 o, V3 d, bool wild)
     c.dxc = readlane_f(d.x, ref); c.dyc = readlane_f(d.y, ref); c.dzc = readlane_f(d.z, ref);
     c.wxyc = readlane_f(wxy, ref); c.wyzc = readlane_f(wyz, ref); c.wzxc = readlane_f(wzx, ref);
     const float z = 0.0f;
-    c.dxr = wave_max(active ? __builtin_fabsf(d.x - c.dxc) : z);
-    c.dyr = wave_max(active ? __builtin_fabsf(d.y - c.dyc) : z);
-    c.dzr = wave_max(active ? __builtin_fabsf(d.z - c.dzc) : z);
-    const float wxyr = wave_max(active ? __builtin_fabsf(wxy - c.wxyc) : z);
-    const float wyzr = wave_max(active ? __builtin_fabsf(wyz - c.wyzc) : z);
-    const float wzxr = wave_max(active ? __builtin_fabsf(wzx - c.wzxc) : z);
-    const float omax = wave_max(active ? __builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fmaxf(__builtin_fabsf(o.y), __builtin_fabsf(o.z))) : z);
-    const float ax = __builtin_fabsf(c.dxc) + c.dxr, ay = __builtin_fabsf(c.dyc) + c.dyr, az = __builtin_fabsf(c.dzc) + c.dzr;
+    // three wave reductions: one radius for the direction, one for the moment, one origin magnitude
+    const float dr = __builtin_fmaxf(__builtin_fabsf(d.x - c.dxc), __builtin_fmaxf(__builtin_fabsf(d.y - c.dyc), __builtin_fabsf(d.z - c.dzc)));
+    const float wr = __builtin_fmaxf(__builtin_fabsf(wxy - c.wxyc), __builtin_fmaxf(__builtin_fabsf(wyz - c.wyzc), __builtin_fabsf(wzx - c.wzxc)));
+    const float om = __builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fmaxf(__builtin_fabsf(o.y), __builtin_fabsf(o.z)));
+    c.dr = wave_max(active ? dr : z);
+    const float wrm = wave_max(active ? wr : z);
+    const float omax = wave_max(active ? om : z);
+    const float ax = __builtin_fabsf(c.dxc) + c.dr, ay = __builtin_fabsf(c.dyc) + c.dr, az = __builtin_fabsf(c.dzc) + c.dr;
     c.sxy = ax + ay; c.syz = ay + az; c.szx = az + ax;
     // Rounding slack.  Sources (u = 2^-24, B = largest bound magnitude, O = omax, D = ax+ay+az >= |d_c|):
     //   this test's own fma chains and the per-lane moments      <= ~12 u (B + O) D
     //   the reference's rounded t values vs exact arithmetic      <= ~12 u (B + O) D   (see cube_slab_approx)
     // 2^-17 (B + O + 1) max(D, 1) = 128 u (...) covers both several times over.
     const float slack = 0x1p-17f * (P.bound_max + omax + 1.0f) * __builtin_fmaxf(ax + ay + az, 1.0f);
-    c.wxyr = wxyr + slack; c.wyzr = wyzr + slack; c.wzxr = wzxr + slack;
+    c.wr = wrm + slack;
     return c;
 }
 
 // lane-private cube (kx,ky,kz,h): true -> some active ray of the wave may pass the slab test
 DEV bool cull_test(f32x4 k, const CullPre& c)
 {
+    const float akx = __builtin_fabsf(k[0]), aky = __builtin_fabsf(k[1]), akz = __builtin_fabsf(k[2]);
     const float gxy = __builtin_fmaf(k[0], c.dyc, __builtin_fmaf(-k[1], c.dxc, -c.wxyc));
-    const float lxy = __builtin_fmaf(k[3], c.sxy, __builtin_fmaf(__builtin_fabsf(k[0]), c.dyr, __builtin_fmaf(__builtin_fabsf(k[1]), c.dxr, c.wxyr)));
+    const float lxy = __builtin_fmaf(k[3], c.sxy, __builtin_fmaf(akx + aky, c.dr, c.wr));
     const float gyz = __builtin_fmaf(k[1], c.dzc, __builtin_fmaf(-k[2], c.dyc, -c.wyzc));
-    const float lyz = __builtin_fmaf(k[3], c.syz, __builtin_fmaf(__builtin_fabsf(k[1]), c.dzr, __builtin_fmaf(__builtin_fabsf(k[2]), c.dyr, c.wyzr)));
+    const float lyz = __builtin_fmaf(k[3], c.syz, __builtin_fmaf(aky + akz, c.dr, c.wr));
     const float gzx = __builtin_fmaf(k[2], c.dxc, __builtin_fmaf(-k[0], c.dzc, -c.wzxc));
-    const float lzx = __builtin_fmaf(k[3], c.szx, __builtin_fmaf(__builtin_fabsf(k[2]), c.dxr, __builtin_fmaf(__builtin_fabsf(k[0]), c.dzr, c.wzxr)));
+    const float lzx = __builtin_fmaf(k[3], c.szx, __builtin_fmaf(akz + akx, c.dr, c.wr));
     const bool sep = (__builtin_fabsf(gxy) > lxy) || (__builtin_fabsf(gyz) > lyz) || (__builtin_fabsf(gzx) > lzx);
     return c.all || !sep;  // NaN compares false -> candidate
 }
