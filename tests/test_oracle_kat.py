@@ -1,0 +1,168 @@
+"""CPU tests of the oracle (oracle/rt_oracle.c): the reference's own known-answer tests, hand-computed
+cases for every restated function, an independent numpy cross-check, and the committed golden frame.
+
+Pinning status: only Color*f32 is pinned by the reference's own tests (src/color.rs:155-177); every
+other check here is a hand-derived expectation or a second restatement ("parity unpinned")."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import raytracing_amd as rt
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---- reference src/color.rs:155-177, restated verbatim
+def test_multiply_by_negative(oracle_mod):
+    assert oracle_mod.color_mul(0x056401, -1.5) == 0x000000  # Color::new(5,100,1) * -1.5
+
+
+def test_multiply_by_large_number(oracle_mod):
+    assert oracle_mod.color_mul(0xFF6401, 100000.0) == 0xFFFFFF  # Color::new(255,100,1) * 100000.0
+
+
+def test_color_ops(oracle_mod):
+    assert oracle_mod.color_mul(0x0A141E, 0.55) == 0x050B10  # truncation: 5.5, 11.0, 16.5
+    assert oracle_mod.color_mul(0x0A141E, float("nan")) == 0  # NaN as u8 == 0
+    assert oracle_mod.color_add(0xF0F0F0, 0x101112) == 0xFFFFFF  # saturating
+    assert oracle_mod.color_add(0x010203, 0x040506) == 0x050709
+    assert oracle_mod.color_sub(0x010203, 0x040201) == 0x000002
+    # the host mirror implements the same operators
+    h = rt._ffi.host()
+    for c, f in [(0x056401, -1.5), (0xFF6401, 100000.0), (0x0A141E, 0.55), (0x87CEEB, 0.95)]:
+        assert h.rth_color_mul(c, f) == oracle_mod.color_mul(c, f)
+    assert h.rth_color_add(0xF0F0F0, 0x101112) == 0xFFFFFF and h.rth_color_sub(0x010203, 0x040201) == 0x000002
+
+
+# ---- reference src/cube.rs:77-218
+def test_cube_front_face(oracle_mod):
+    hit, dist, px, py, pz, nx, ny, nz, u, v, face = oracle_mod.cube_intersect([0, 0, 0], 1.5, [0.25, 0.5, 10], [0, 0, -1])
+    assert hit == 1 and dist == 9.25 and (px, py, pz) == (0.25, 0.5, 0.75)
+    assert (nx, ny, nz) == (0, 0, 1) and face == 3  # FORWARDS
+    assert u == pytest.approx((0.25 + 0.75) / 1.5) and v == pytest.approx((0.5 + 0.75) / 1.5)
+
+
+def test_cube_behind_origin_is_a_hit_with_negative_distance(oracle_mod):
+    # cube.rs:145 has no tmax < 0 rejection: a cube behind the ray still returns Some, distance = tmax < 0
+    hit, dist, *_ = oracle_mod.cube_intersect([0, 0, 20], 1.5, [0, 0, 10], [0, 0, -1])
+    assert hit == 1 and dist == -9.25
+
+
+def test_cube_miss_and_zero_direction_component(oracle_mod):
+    assert oracle_mod.cube_intersect([5, 0, 0], 1.5, [0, 0, 10], [0, 0, -1])[0] == 0  # d.x = 0, origin outside x slab
+    assert oracle_mod.cube_intersect([0.5, 0, 0], 1.5, [0, 0, 10], [0, 0, -1])[0] == 1  # inside the x slab: +-inf
+    r = oracle_mod.cube_intersect([0, 0, 0], 1.5, [-10, 0.1, 0.2], [1, 0, 0])
+    assert r[0] == 1 and r[10] == 5 and r[1] == 9.25  # LEFT face
+    r = oracle_mod.cube_intersect([0, 0, 0], 1.5, [0.1, 10, 0.2], [0, -1, 0])
+    assert r[0] == 1 and r[10] == 1  # TOP
+
+
+def test_cube_inside_origin_uses_tmax(oracle_mod):
+    r = oracle_mod.cube_intersect([0, 0, 0], 1.5, [0, 0, 0], [0, 0, -1])
+    assert r[0] == 1 and r[1] == 0.75 and r[10] == 4  # exits through BACKWARDS (z min)
+
+
+# ---- reference src/sphere.rs:25-56
+def test_sphere(oracle_mod):
+    r = oracle_mod.sphere_intersect([0, 0, 0], 1.0, [0, 0, 5], [0, 0, -1])
+    assert r[0] == 1 and r[1] == 4.0 and (r[5], r[6], r[7]) == (0, 0, 1) and r[10] == 0
+    assert oracle_mod.sphere_intersect([0, 0, 0], 1.0, [0, 0, 0], [0, 0, -1])[0] == 0  # inside: near root negative
+    assert oracle_mod.sphere_intersect([0, 0, 0], 1.0, [1, 0, 5], [0, 0, -1])[0] == 0  # tangent: discriminant == 0
+    assert oracle_mod.sphere_intersect([0, 0, 0], 1.0, [0, 0, -5], [0, 0, -1])[0] == 0  # behind
+
+
+# ---- reference src/render.rs:17-42
+def test_reflect_refract(oracle_mod):
+    assert oracle_mod.reflect([1, -1, 0], [0, 1, 0]) == [1, 1, 0]
+    # straight through along -n: cosi = 1 -> k = 1 - eta^2*0 = 1 -> eta*i + (eta - 1)*n
+    out = oracle_mod.refract([0, -1, 0], [0, 1, 0], 1.25)
+    assert out == pytest.approx([0, -1.25 + 0.25, 0])
+    # cosi < 0 branch: ray along +n flips the normal and inverts eta (the reference's inverted convention)
+    out = oracle_mod.refract([0, 1, 0], [0, 1, 0], 1.25)
+    assert out == pytest.approx([0, 0.8 - (0.8 - 1.0), 0])
+
+
+# ---- reference src/texture.rs:178-196
+def test_texel_lookup(oracle_mod, default_scene):
+    O = oracle_mod.OracleScene(default_scene)
+    a = default_scene.atlas
+    hexof = lambda t, x, y: (int(a[t, y, x, 0]) << 16) | (int(a[t, y, x, 1]) << 8) | int(a[t, y, x, 2])
+    tex = 7  # MAGMA
+    assert O.texel(tex, 1, 3.7, 2.2) == hexof(tex, 16 + 3, 16 + 2)      # TOP      origin (16,16)
+    assert O.texel(tex, 2, 0.0, 15.99) == hexof(tex, 16, 48 + 15)       # BOTTOM   origin (16,48)
+    assert O.texel(tex, 3, 99.0, -5.0) == hexof(tex, 31, 0)             # FORWARDS origin (16,0), clamped
+    assert O.texel(tex, 4, 1.0, 1.0) == hexof(tex, 17, 33)              # BACKWARDS origin (16,32)
+    assert O.texel(tex, 5, 15.5, 0.5) == hexof(tex, 15, 16)             # LEFT     origin (0,16)
+    assert O.texel(tex, 6, 0.5, 15.5) == hexof(tex, 32, 31)             # RIGHT    origin (32,16)
+    assert O.texel(tex, 0, 1.0, 1.0) == 0xFF00FF                        # NONE
+    assert O.texel(tex, 1, float("nan"), 0.0) == hexof(tex, 0, 16)      # NaN as u32 == 0
+
+
+# ---- reference src/camera.rs
+def test_change_basis_and_rotate(oracle_mod, default_scene):
+    cam = default_scene.camera  # eye (0,0,10) -> origin, up +Y
+    assert oracle_mod.change_basis(cam, [0, 0, -1]) == [0, 0, -1]
+    assert oracle_mod.change_basis(cam, [1, 0, 0]) == [1, 0, 0]
+    c2 = oracle_mod.rotate_cam(cam, 0.5, -0.25)
+    h2 = rt.rotate_cam(cam, 0.5, -0.25)  # C++ host mirror
+    assert (c2.eye.x, c2.eye.y, c2.eye.z) == (h2.eye.x, h2.eye.y, h2.eye.z)
+    r = np.sqrt(c2.eye.x ** 2 + c2.eye.y ** 2 + c2.eye.z ** 2)
+    assert r == pytest.approx(10.0, rel=1e-6)
+    c3 = oracle_mod.rotate_cam(cam, 0.0, 10.0)  # pitch clamps at pi/2 - 0.1
+    assert np.arctan2(-c3.eye.y, np.hypot(c3.eye.x, c3.eye.z)) == pytest.approx(np.pi / 2 - 0.1, abs=1e-5)
+
+
+# ---- reference src/bmp.rs
+def test_bmp_layout(oracle_mod):
+    w, h = 3, 2
+    buf = np.array([[0x010203, 0x040506, 0x070809], [0x0A0B0C, 0x0D0E0F, 0x101112]], dtype=np.uint32)
+    img = oracle_mod.bmp_encode(buf, w, h)
+    assert img[:2] == b"BM" and len(img) == 54 + 2 * 12
+    assert int.from_bytes(img[2:6], "little") == len(img) and int.from_bytes(img[10:14], "little") == 54
+    assert int.from_bytes(img[14:18], "little") == 40 and int.from_bytes(img[18:22], "little") == w
+    assert int.from_bytes(img[22:26], "little") == h and img[26:28] == b"\x01\x00" and img[28:30] == b"\x18\x00"
+    # bottom-up rows, BGR, 3 bytes of padding per 9-byte row
+    assert img[54:66] == bytes([0x0C, 0x0B, 0x0A, 0x0F, 0x0E, 0x0D, 0x12, 0x11, 0x10, 0, 0, 0])
+    assert img[66:78] == bytes([0x03, 0x02, 0x01, 0x06, 0x05, 0x04, 0x09, 0x08, 0x07, 0, 0, 0])
+    assert rt.bmp_encode(buf, w, h) == img  # C++ host writer is byte-identical
+    from PIL import Image
+    import io
+    dec = np.asarray(Image.open(io.BytesIO(img)).convert("RGB"))
+    assert dec[0, 0].tolist() == [1, 2, 3] and dec[1, 2].tolist() == [0x10, 0x11, 0x12]
+
+
+# ---- whole-frame properties of the oracle
+def test_unpainted_pixel_and_modes_agree(oracle_mod, default_scene):
+    O = oracle_mod.OracleScene(default_scene)
+    f = default_scene.frame(96, 64)
+    lit, pl, cl, _ = O.render(f, debug=True, reuse_secondary=False, threads=4)
+    uni, pu, cu, _ = O.render(f, debug=True, reuse_secondary=True, threads=4)
+    assert lit[1, 0] == 0 and lit[0, 0] == default_scene.sky_0rgb  # render.rs:316-322
+    assert np.array_equal(lit, uni)  # tracing secondaries once per hit changes nothing
+    for k in pl:
+        assert np.array_equal(pl[k], pu[k])
+    assert cl.nearest_rays >= cu.nearest_rays and cl.shadow_rays >= cu.shadow_rays
+    # bands and row sampling address the same pixels
+    band, *_ = O.render(default_scene.frame(96, 64, y0=20, y1=40), threads=2)
+    assert np.array_equal(band, lit[20:40])
+
+
+def test_numpy_restatement_agrees_on_hit_indices(oracle_mod, default_scene):
+    import np_restatement
+    w, h = 135, 90
+    _, planes, _, _ = oracle_mod.OracleScene(default_scene).render(default_scene.frame(w, h), debug=True, threads=4)
+    assert np.array_equal(np_restatement.nearest_cube(default_scene, w, h), planes["hit_cube"])
+
+
+def test_golden_frame(oracle_mod, default_scene):
+    """tests/golden/minecraft_270x180.npz was produced by tools/make_golden.py from this oracle; it pins the
+    oracle against accidental change and gives the GPU tests a fixture that needs no oracle run."""
+    g = np.load(os.path.join(GOLDEN, "minecraft_270x180.npz"))
+    fb, planes, cnt, _ = oracle_mod.OracleScene(default_scene).render(default_scene.frame(270, 180), debug=True, reuse_secondary=True)
+    assert np.array_equal(fb, g["fb"])
+    for k in ("hit_cube", "hit_sphere", "tree_hash"):
+        assert np.array_equal(planes[k], g[k])
+    assert hashlib.sha256(rt.bmp_encode(fb, 270, 180)).hexdigest() == str(g["bmp_sha256"])
