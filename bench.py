@@ -118,17 +118,18 @@ def main():
     frame = scene.frame(W, H)
     n_lights = len(scene.lights)
 
-    my_rows = rt.part_rows(H, world, rank)
-    max_rows = max(rt.part_rows(H, world, r) for r in range(world))
-    out = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)  # padded so every rank sends the same size
-    gather_list = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
-    ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)  # order the gather after the render on the library's stream
+    from raytracing_amd.multigpu import FrameGather
+    # order the gather (and rank 0's row scatter) after the render on the library's own stream
+    ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+    with torch.cuda.stream(ext):
+        fg = FrameGather(H, W, world, rank, dev)
+    out = fg.local  # [max_part_rows, W] int32, padded so every rank sends the same size
 
     def step():
         ctx.render_device(frame, out.data_ptr(), n_parts=world, part=rank)
         if world > 1:
             with torch.cuda.stream(ext):
-                dist.gather(out, gather_list, dst=0)
+                fg.gather()  # RCCL gather to GPU0 + scatter of the 16-row blocks into frame order
 
     def sync():
         ctx.sync()

@@ -81,3 +81,97 @@ def test_night_and_orbit_match_oracle(gpu_ctx, oracle_mod, default_scene):
                      s.tex_h, s.sprite, "night")
     f, gfb, gpl, ofb, opl, _ = _both(gpu_ctx, oracle_mod, night, 300, 200)
     assert_parity(gfb, gpl, ofb, opl, "night orbit")
+
+
+def test_golden_fixtures(gpu_ctx):
+    """GPU vs the committed oracle outputs (tests/golden/*.npz, made by tools/make_golden.py)."""
+    import os
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    cases = [("minecraft_270x180.npz", rt.default_scene(), 270, 180),
+             ("minecraft_water_240x135.npz", rt.default_scene(with_water=True), 240, 135),
+             ("synthetic_600c_24s_160x90.npz", rt.synthetic_scene(n_cubes=600, n_spheres=24), 160, 90)]
+    for name, scene, w, h in cases:
+        g = np.load(os.path.join(gdir, name))
+        gpu_ctx.upload(scene)
+        f = scene.frame(w, h)
+        fb, planes = gpu_ctx.render(f, debug=True)
+        assert_parity(fb, planes, g["fb"], {k: g[k] for k in ("hit_cube", "hit_sphere", "tree_hash")}, name)
+        c = gpu_ctx.count_rays(f)
+        assert list(c.uniq_dict().values()) == g["uniq"].tolist()
+        assert list(c.ref_dict().values()) == g["ref"].tolist()  # n_lights^depth weighting == the reference's re-casting
+
+
+def test_interleaved_parts_reassemble(gpu_ctx, default_scene):
+    """rt_render_device_part for every part of an N-way split == the whole frame (N-GPU path on one GPU)."""
+    import torch
+    from raytracing_amd import multigpu
+    gpu_ctx.upload(default_scene)
+    w, h = 200, 150
+    f = default_scene.frame(w, h)
+    full = gpu_ctx.render(f)
+    for n in (2, 3, 8):
+        frame = np.zeros((h, w), dtype=np.uint32)
+        total = rt.Counters()
+        for p in range(n):
+            rows = multigpu.part_rows(h, n, p)
+            buf = torch.zeros((multigpu.max_part_rows(h, n), w), dtype=torch.int32, device="cuda")
+            gpu_ctx.render_device(f, buf.data_ptr(), n_parts=n, part=p)
+            gpu_ctx.sync()
+            frame[multigpu.part_row_indices(h, n, p)] = buf[:rows].cpu().numpy().view(np.uint32)
+        assert np.array_equal(frame, full)
+        parts = [gpu_ctx.count_rays(f, n_parts=n, part=p) for p in range(n)]
+        assert sum(c.rays for c in parts) == gpu_ctx.count_rays(f).rays
+
+
+def test_host_mirror_render_path(default_scene, gpu_ctx):
+    """raytracer::render(framebuffer, model) of the C++ host mirror == direct C-ABI calls."""
+    import ctypes as C
+    h = rt._ffi.host()
+    w, hh = 160, 100
+    out = np.zeros((hh, w), dtype=np.uint32)
+    assert h.rth_render(default_scene._model, w, hh, out.ctypes.data_as(C.c_void_p), None, None, None) == 0, h.rth_last_error()
+    gpu_ctx.upload(default_scene)
+    assert np.array_equal(out, gpu_ctx.render(default_scene.frame(w, hh)))
+
+
+def test_full_size_properties(gpu_ctx, default_scene):
+    """Size-independent checks at BASELINE sizes (no oracle run): bands of the 4K frame equal the full frame,
+    the sky rows are sky, the unpainted pixel is black, counters are consistent."""
+    gpu_ctx.upload(default_scene)
+    W, H = 3840, 2160
+    full = gpu_ctx.render(default_scene.frame(W, H))
+    assert full[1, 0] == 0 and (full[:400] == default_scene.sky_0rgb).sum() == 400 * W - 1
+    band = gpu_ctx.render(default_scene.frame(W, H, y0=1000, y1=1100))
+    assert np.array_equal(band, full[1000:1100])
+    c = gpu_ctx.count_rays(default_scene.frame(W, H))
+    assert c.nearest_rays >= 2 * W * H and c.cube_tests >= W * H * default_scene.n_cubes
+    assert c.ref_rays >= c.rays and c.shadow_rays == 2 * c.shaded_hits
+
+
+def test_error_paths(gpu_ctx, default_scene):
+    gpu_ctx.upload(default_scene)
+    f = default_scene.frame(64, 48)
+    f.max_depth = 4
+    with pytest.raises(rt.RtError) as e:
+        gpu_ctx.render(f)
+    assert e.value.code == rt._ffi.RT_ERR_UNSUPPORTED
+    f = default_scene.frame(64, 48, y0=30, y1=30)
+    with pytest.raises(rt.RtError) as e:
+        gpu_ctx.render(f)
+    assert e.value.code == rt._ffi.RT_ERR_INVALID_ARG
+    with rt.Context(0) as fresh:
+        with pytest.raises(rt.RtError) as e:
+            fresh.render(default_scene.frame(8, 8))
+        assert e.value.code == rt._ffi.RT_ERR_NO_SCENE
+
+
+def test_empty_scene_and_ragged_sizes(gpu_ctx, oracle_mod, default_scene):
+    """Edge cases: no objects at all, a frame that is not a multiple of the 16x16 tile, a 1-row frame."""
+    s = default_scene
+    empty = rt.make_scene([], [], [s.materials[0]], list(s.lights), s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
+    gpu_ctx.upload(empty)
+    fb = gpu_ctx.render(empty.frame(37, 19))
+    assert fb[1, 0] == 0 and (fb == s.sky_0rgb).sum() == 37 * 19 - 1
+    for w, h in [(37, 19), (129, 1), (1, 5), (17, 33)]:
+        f, gfb, gpl, ofb, opl, _ = _both(gpu_ctx, oracle_mod, s, w, h)
+        assert_parity(gfb, gpl, ofb, opl, f"ragged {w}x{h}")
