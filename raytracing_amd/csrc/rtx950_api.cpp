@@ -7,7 +7,10 @@
 // with RT_ERR_NO_DEVICE / RT_ERR_HIP.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -46,6 +49,13 @@ struct rt_ctx {
 };
 
 namespace {
+
+#ifdef RTX_PROFILE
+constexpr size_t kProfWaves = 4u << 20;  // per-wave phase slots of the diagnostic build
+constexpr size_t kCounterBytes = 256 + kProfWaves * 10 * sizeof(uint32_t);
+#else
+constexpr size_t kCounterBytes = 32 * sizeof(unsigned long long);
+#endif
 
 thread_local std::string g_tls_err;
 
@@ -218,7 +228,7 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
         delete c;
         return fail_hip(nullptr, e, "hipStreamCreateWithFlags");
     }
-    e = hipMalloc((void**)&c->d_counters, 16 * sizeof(unsigned long long));
+    e = hipMalloc((void**)&c->d_counters, kCounterBytes);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
@@ -378,6 +388,9 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
     p.n_parts = n_parts;
     p.part = part;
     p.out = d_out_0rgb;
+#ifdef RTX_PROFILE
+    p.counters = ctx->d_counters;
+#endif
     int variant = kVariantRender;
     if (dbg_device && (dbg_device->hit_cube || dbg_device->hit_sphere || dbg_device->tree_hash)) {
         p.hit_cube = dbg_device->hit_cube;
@@ -479,6 +492,39 @@ int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches)
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
         total += ms;
     }
+#ifdef RTX_PROFILE
+    {
+        std::vector<uint32_t> h(kProfWaves * 10);
+        HIP_TRY(ctx, hipMemcpy(h.data(), (char*)ctx->d_counters + 256, h.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemset((char*)ctx->d_counters + 256, 0, h.size() * 4));
+        const char* names[10] = {"raygen", "pre(ray_pre+cull_pre)", "cull(+chunk load wait)", "candidates", "contested", "resolve", "shade", "shadow_post", "childsetup", "other"};
+        double sum[10] = {0}; double tot = 0; size_t waves = 0; double mx = 0;
+        for (size_t w = 0; w < kProfWaves; ++w) {
+            double t = 0;
+            for (int k = 0; k < 10; ++k) { sum[k] += h[w * 10 + k]; t += h[w * 10 + k]; }
+            if (t > 0) { ++waves; tot += t; if (t > mx) mx = t; }
+        }
+        fprintf(stderr, "[rtx950 profile, last launch] waves=%zu avg wave-cycles=%.0f max=%.0f\n", waves, tot / (waves ? waves : 1), mx);
+        {   // slowest waves: tile position and phase split
+            std::vector<std::pair<double, size_t>> top;
+            for (size_t w = 0; w < kProfWaves; ++w) { double t = 0; for (int k = 0; k < 10; ++k) t += h[w * 10 + k]; if (t > 0) top.push_back({t, w}); }
+            std::sort(top.begin(), top.end()); std::reverse(top.begin(), top.end());
+            const size_t gx = 240;  // 3840/16 (diagnostic assumes the 4K bench frame)
+            for (size_t i = 0; i < top.size() && i < 12; ++i) {
+                size_t w = top[i].second, blk = w / 4, wv = w % 4;
+                fprintf(stderr, "  slow wave %zu: tile x=%zu y=%zu cyc=%.0f :", i, (blk % gx) * 16 + (wv & 1) * 8, (blk / gx) * 16 + (wv >> 1) * 8, top[i].first);
+                for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", h[w * 10 + k]);
+                fprintf(stderr, "\n");
+            }
+            if (const char* dump = getenv("RTX950_PROF_DUMP")) {
+                if (FILE* f = fopen(dump, "wb")) { fwrite(h.data(), 4, (size_t)129600 * 10, f); fclose(f); }
+            }
+            size_t hist[8] = {0}; for (auto& t : top) { int b = 0; double v = t.first; while (v > 8192 && b < 7) { v /= 2; ++b; } hist[b]++; }
+            fprintf(stderr, "  histogram of wave cycles (<=8K,16K,32K,64K,128K,256K,512K,more):"); for (int b = 0; b < 8; ++b) fprintf(stderr, " %zu", hist[b]); fprintf(stderr, "\n");
+        }
+        for (int k = 0; k < 10; ++k) fprintf(stderr, "  %-24s %6.2f %%  %8.0f cyc/wave\n", names[k], 100.0 * sum[k] / (tot > 0 ? tot : 1), sum[k] / (double)(waves ? waves : 1));
+    }
+#endif
     *out_launches = (uint32_t)ctx->events.size();
     *out_avg_ms = ctx->events.empty() ? 0.0 : total / (double)ctx->events.size();
     for (auto& ev : ctx->events) ctx->event_pool.push_back(ev);

@@ -400,12 +400,46 @@ DEV float powf_like_libm(float x, float y)
     const bool one = (x == 1.0f);
     const bool ident = (y == 1.0f);
     float r = zero ? 0.0f : (one ? 1.0f : x);
-    const bool full = !(zero || one || ident);
+    bool full = !(zero || one || ident);
+    // The only consumer is (light.color * albedo.1) * spec * intensity with u8 truncation after every
+    // product (render.rs:149-152, color.rs:118-130): any spec < 1/255 turns a channel <= 255 into 0.
+    // A 3-instruction estimate exp2(y*log2 x) (v_log_f32/v_exp_f32, 1 ulp each; relative error of the
+    // result <= ~2^-22 * (1 + |y log2 x|) < 1e-3 for |y log2 x| < 2^12) proves that for most pixels, and
+    // the estimate itself (< 2^-9) is then returned: it yields the same zeros as the exact value.
+    if (full && x > 0.0f && x < 1.0f && y > 0.0f) {
+        const float e = y * __builtin_amdgcn_logf(x);
+        const float est = __builtin_amdgcn_exp2f(e);
+        if (est < 0x1p-9f && e > -4096.0f) {
+            r = est;
+            full = false;
+        } else if (!(e > -4096.0f)) {  // far below the smallest subnormal: powf underflows to +0 as well
+            r = 0.0f;
+            full = false;
+        }
+    }
     if (__builtin_amdgcn_ballot_w64(full) != 0ull) {
         if (full) r = (float)pow((double)x, (double)y);
     }
     return r;
 }
+
+// ---------------------------------------------------------------- diagnostic build: per-phase cycle shares
+// -DRTX_PROFILE adds s_memtime stamps around the phases of a traversal; the per-wave sums go to
+// P.counters[16..] (memory no output depends on).  Never enabled in the shipped library.
+#ifdef RTX_PROFILE
+struct Prof { uint32_t t[10]; uint32_t last; };
+__device__ Prof* g_prof_unused;
+#define PROF_DECL Prof prof; for (int k_ = 0; k_ < 10; ++k_) prof.t[k_] = 0u; prof.last = (uint32_t)__builtin_readcyclecounter();
+#define PROF_ARG , Prof& prof
+#define PROF_PASS , prof
+#define PROF_MARK(k) do { uint32_t n_ = (uint32_t)__builtin_readcyclecounter(); prof.t[k] += n_ - prof.last; prof.last = n_; } while (0)
+#else
+#define PROF_DECL
+#define PROF_ARG
+#define PROF_PASS
+#define PROF_MARK(k) do { } while (0)
+#endif
+enum { PH_RAYGEN = 0, PH_PRE = 1, PH_CULL = 2, PH_CAND = 3, PH_CONTESTED = 4, PH_RESOLVE = 5, PH_SHADE = 6, PH_SHADOW_POST = 7, PH_CHILDSETUP = 8, PH_OTHER = 9 };
 
 // ---------------------------------------------------------------- wave-level helpers
 // Everything from here on runs with all 64 lanes enabled: control flow depends only on wave-uniform
@@ -519,13 +553,14 @@ struct QState {
 //   Q_NEAREST_EXACT  exact evaluation of every candidate for the lanes in `active`.
 //   Q_SHADOW         render.rs:44-70 list-order semantics, exclusion by id (render.rs:113).
 template <int MODE>
-DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st)
+DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
     const uint32_t n = P.n_cubes;
     if (n == 0u) return;
     const RayPre q = ray_pre(P, o, d);
     st.tol = q.tol;
     const CullPre cp = cull_pre(P, active, o, d, q.wild);
+    PROF_MARK(PH_PRE);
     const uint32_t lane = threadIdx.x & 63u;
     const f32x4* filt = (const f32x4*)P.cube_filt;
     f32x4 rec = filt[lane];
@@ -536,6 +571,7 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
         uint32_t ids = 0u;
         if constexpr (MODE == Q_SHADOW) ids = P.cube_id[base + lane];
         unsigned long long M = wave_ballot(cull_test(rec, cp) && (base + lane < n));
+        PROF_MARK(PH_CULL);
         while (M != 0ull) {
             const uint32_t b = (uint32_t)__builtin_ctzll(M);
             M &= M - 1ull;
@@ -585,25 +621,27 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
                 }
             }
         }
+        PROF_MARK(PH_CAND);
         rec = nxt;
     }
 }
 
 // ---------------------------------------------------------------- nearest hit (render.rs:87-101)
 template <int PASS, bool COUNT>
-DEV uint32_t nearest_query(const Params& P, bool active, V3 o, V3 d, Counters& cnt)
+DEV uint32_t nearest_query(const Params& P, bool active, V3 o, V3 d, Counters& cnt PROF_ARG)
 {
     uint32_t best_idx = kNoHit;
     if constexpr (PASS == PASS_CUBES) {
         QState st;
         st.b1 = __builtin_inff(); st.b2 = __builtin_inff(); st.i1 = kNoHit;
         st.best = __builtin_inff(); st.best_i = kNoHit; st.done = false; st.blocker = kNoHit; st.tol = 0.0f;
-        cube_query<Q_NEAREST>(P, active, o, d, 0u, st);
+        cube_query<Q_NEAREST>(P, active, o, d, 0u, st PROF_PASS);
         best_idx = active ? st.i1 : kNoHit;
         // contested: a second candidate within 2E of the best (exact duplicates, shared edges).  NaN -> contested.
         const bool contested = active && (st.i1 != kNoHit) && !(st.b2 - st.b1 > st.tol);
         if (wave_any(contested)) {
-            cube_query<Q_NEAREST_EXACT>(P, contested, o, d, 0u, st);
+            cube_query<Q_NEAREST_EXACT>(P, contested, o, d, 0u, st PROF_PASS);
+            PROF_MARK(PH_CONTESTED);
             best_idx = contested ? st.best_i : best_idx;
         }
         if constexpr (COUNT) cnt.cube_tests += active ? P.n_cubes : 0u;
@@ -627,7 +665,7 @@ DEV uint32_t nearest_query(const Params& P, bool active, V3 o, V3 d, Counters& c
 // First object in array order, among those whose id differs from the impact object's
 // (render.rs:113), whose ray_intersect returns Some.  Not the nearest one.
 template <int PASS, bool COUNT>
-DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, uint32_t impact_id, uint32_t& blocker, Counters& cnt)
+DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, uint32_t impact_id, uint32_t& blocker, Counters& cnt PROF_ARG)
 {
     const V3 dir = vnormalize(vsub(light_pos, origin));
     blocker = kNoHit;
@@ -637,7 +675,7 @@ DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, ui
         QState st;
         st.b1 = 0.0f; st.b2 = 0.0f; st.i1 = kNoHit; st.best = 0.0f; st.best_i = kNoHit;
         st.done = false; st.blocker = kNoHit; st.tol = 0.0f;
-        cube_query<Q_SHADOW>(P, active, origin, dir, impact_id, st);
+        cube_query<Q_SHADOW>(P, active, origin, dir, impact_id, st PROF_PASS);
         blocker = (active && st.done) ? st.blocker : kNoHit;
         if (wave_any(blocker != kNoHit)) {
             // the blocker's exact distance (per-lane gather; the loop only proved that it passes)
@@ -683,6 +721,7 @@ DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, ui
         const float sh = sdist / d2 * (1.0f - P.mats[bm].transparency);
         shadow = has ? sh : 0.0f;
     }
+    PROF_MARK(PH_SHADOW_POST);
     return shadow;
 }
 
@@ -696,7 +735,7 @@ DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, ui
 // Predicated form: every lane of the wave executes the call; `active` says whether the lane has a
 // ray.  Results of inactive lanes are unspecified and unused.
 template <int PASS, int DEPTH, bool DBG, bool COUNT>
-DEV Col cast_ray(const Params& P, bool active, V3 o, V3 d, float ambient, uint32_t& hash, uint32_t& hit_idx, Totals& tot)
+DEV Col cast_ray(const Params& P, bool active, V3 o, V3 d, float ambient, uint32_t& hash, uint32_t& hit_idx, Totals& tot PROF_ARG)
 {
     const Col sky = col_from_hex(P.sky);
     hit_idx = kNoHit;
@@ -707,7 +746,8 @@ DEV Col cast_ray(const Params& P, bool active, V3 o, V3 d, float ambient, uint32
         if ((uint32_t)DEPTH > P.max_depth) return sky;  // wave-uniform
         if (!wave_any(active)) return sky;                // wave-uniform
         Counters cnt = {0u, 0u, 0u, 0u, 0u};
-        const uint32_t idx = nearest_query<PASS, COUNT>(P, active, o, d, cnt);
+        PROF_MARK(PH_OTHER);
+        const uint32_t idx = nearest_query<PASS, COUNT>(P, active, o, d, cnt PROF_PASS);
         hit_idx = idx;
         uint32_t h = hmix(kHashBasis, idx);
         Col result = sky;
@@ -719,6 +759,7 @@ DEV Col cast_ray(const Params& P, bool active, V3 o, V3 d, float ambient, uint32
             if constexpr (PASS == PASS_CUBES) hit = cube_resolve(P, sidx, o, d);
             else hit = sphere_resolve(P, sidx, o, d);
             const MatRec m = P.mats[hit.material];
+            PROF_MARK(PH_RESOLVE);
 
             Col tx;
             if (m.texture >= 0) tx = texel_of_face(P, m.texture, hit.face, hit.u * P.sprite, hit.v * P.sprite);
@@ -735,7 +776,8 @@ DEV Col cast_ray(const Params& P, bool active, V3 o, V3 d, float ambient, uint32
                 const V3 light_dir = vnormalize(vsub(lp, hit.p));
                 const V3 reflect_dir = vnormalize(reflect(vneg(light_dir), hit.n));
                 uint32_t blocker;
-                const float shadow = shadow_query<PASS, COUNT>(P, hit_any, hit.p, lp, hit.id, blocker, cnt);
+                PROF_MARK(PH_SHADE);
+                const float shadow = shadow_query<PASS, COUNT>(P, hit_any, hit.p, lp, hit.id, blocker, cnt PROF_PASS);
                 if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
                 const float light_intensity = L.intensity * (1.0f - shadow);
                 const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
@@ -745,6 +787,7 @@ DEV Col cast_ray(const Params& P, bool active, V3 o, V3 d, float ambient, uint32
                 sum = col_add(sum, col_mul(col_add(diffuse, specular), k_ds));
             }
 
+            PROF_MARK(PH_SHADE);
             // children (render.rs:154-193)
             const bool has_refl = hit_any && (m.reflectivity > 0.0f);
             const bool has_refr = hit_any && (m.transparency > 0.0f);
@@ -765,7 +808,8 @@ DEV Col cast_ray(const Params& P, bool active, V3 o, V3 d, float ambient, uint32
                     const V3 co = is_refl ? refl_o : refr_o;
                     const V3 cd = is_refl ? refl_d : refr_d;
                     uint32_t ch, cidx;
-                    const Col cc = cast_ray<PASS, DEPTH + 1, DBG, COUNT>(P, child, co, cd, ambient, ch, cidx, tot);
+                    PROF_MARK(PH_CHILDSETUP);
+                    const Col cc = cast_ray<PASS, DEPTH + 1, DBG, COUNT>(P, child, co, cd, ambient, ch, cidx, tot PROF_PASS);
                     if (child && is_refl) { c_refl = cc; h_refl = ch; }
                     if (child && !is_refl) { c_refr = cc; h_refr = ch; }
                 }
@@ -815,6 +859,7 @@ __global__ __launch_bounds__(256, RTX_MIN_WAVES) void render_kernel(const Params
     Totals cnt;
 #pragma unroll
     for (int k = 0; k < 10; ++k) cnt.v[k] = 0ull;
+    PROF_DECL
     const bool active = (x < P.width) && (y < P.y1);  // lanes outside the frame stay in the wave, inactive
 
     const float width = (float)P.width, height = (float)P.height;
@@ -831,8 +876,10 @@ __global__ __launch_bounds__(256, RTX_MIN_WAVES) void render_kernel(const Params
     const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
 
     uint32_t hs, hc, hit_s, hit_c;
-    const Col cs = cast_ray<PASS_SPHERES, 0, DBG, COUNT>(P, active, eye, dir, 1.0f, hs, hit_s, cnt);
-    const Col cc = cast_ray<PASS_CUBES, 0, DBG, COUNT>(P, active, eye, dir, P.ambient, hc, hit_c, cnt);
+    PROF_MARK(PH_RAYGEN);
+    const Col cs = cast_ray<PASS_SPHERES, 0, DBG, COUNT>(P, active, eye, dir, 1.0f, hs, hit_s, cnt PROF_PASS);
+    const Col cc = cast_ray<PASS_CUBES, 0, DBG, COUNT>(P, active, eye, dir, P.ambient, hc, hit_c, cnt PROF_PASS);
+    PROF_MARK(PH_OTHER);
     const uint32_t s_hex = col_to_hex(cs);
     uint32_t px = (s_hex == P.sky) ? col_to_hex(cc) : s_hex;  // render.rs:308-312
     const size_t i_frame = (size_t)y * P.width + x;
@@ -848,6 +895,14 @@ __global__ __launch_bounds__(256, RTX_MIN_WAVES) void render_kernel(const Params
             if (P.tree_hash) P.tree_hash[i_band] = hmix(hmix(kHashBasis, hs), hc);
         }
     }
+#ifdef RTX_PROFILE
+    PROF_MARK(PH_OTHER);
+    if (lane == 0u && P.counters) {
+        // per-wave slots (no atomics: contended atomics would dominate the run); the host sums them
+        uint32_t* slot = (uint32_t*)P.counters + 64 + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave) * 10u;
+        for (int k = 0; k < 10; ++k) slot[k] = prof.t[k];
+    }
+#endif
     if constexpr (COUNT) {
         // wave reduction, then one atomic per wave and counter
 #pragma unroll
