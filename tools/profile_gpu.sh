@@ -4,6 +4,7 @@
 set -e -o pipefail
 TAG=${1:-r1}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
+rm -rf "$OUT"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH_ARGS="--steps 10 --warmup 2 --cpu-seconds 0 $*"
