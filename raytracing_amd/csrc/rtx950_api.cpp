@@ -52,7 +52,7 @@ namespace {
 
 #ifdef RTX_PROFILE
 constexpr size_t kProfWaves = 4u << 20;  // per-wave phase slots of the diagnostic build
-constexpr size_t kCounterBytes = 256 + kProfWaves * 10 * sizeof(uint32_t);
+constexpr size_t kCounterBytes = 256 + kProfWaves * 16 * sizeof(uint32_t);
 #else
 constexpr size_t kCounterBytes = 32 * sizeof(unsigned long long);
 #endif
@@ -494,30 +494,30 @@ int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches)
     }
 #ifdef RTX_PROFILE
     {
-        std::vector<uint32_t> h(kProfWaves * 10);
+        std::vector<uint32_t> h(kProfWaves * 16);
         HIP_TRY(ctx, hipMemcpy(h.data(), (char*)ctx->d_counters + 256, h.size() * 4, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemset((char*)ctx->d_counters + 256, 0, h.size() * 4));
         const char* names[10] = {"raygen", "pre(ray_pre+cull_pre)", "cull(+chunk load wait)", "candidates", "contested", "resolve", "shade", "shadow_post", "childsetup", "other"};
         double sum[10] = {0}; double tot = 0; size_t waves = 0; double mx = 0;
         for (size_t w = 0; w < kProfWaves; ++w) {
             double t = 0;
-            for (int k = 0; k < 10; ++k) { sum[k] += h[w * 10 + k]; t += h[w * 10 + k]; }
+            for (int k = 0; k < 10; ++k) { sum[k] += h[w * 16 + k]; t += h[w * 16 + k]; }
             if (t > 0) { ++waves; tot += t; if (t > mx) mx = t; }
         }
         fprintf(stderr, "[rtx950 profile, last launch] waves=%zu avg wave-cycles=%.0f max=%.0f\n", waves, tot / (waves ? waves : 1), mx);
         {   // slowest waves: tile position and phase split
             std::vector<std::pair<double, size_t>> top;
-            for (size_t w = 0; w < kProfWaves; ++w) { double t = 0; for (int k = 0; k < 10; ++k) t += h[w * 10 + k]; if (t > 0) top.push_back({t, w}); }
+            for (size_t w = 0; w < kProfWaves; ++w) { double t = 0; for (int k = 0; k < 10; ++k) t += h[w * 16 + k]; if (t > 0) top.push_back({t, w}); }
             std::sort(top.begin(), top.end()); std::reverse(top.begin(), top.end());
             const size_t gx = 240;  // 3840/16 (diagnostic assumes the 4K bench frame)
             for (size_t i = 0; i < top.size() && i < 12; ++i) {
                 size_t w = top[i].second, blk = w / 4, wv = w % 4;
                 fprintf(stderr, "  slow wave %zu: tile x=%zu y=%zu cyc=%.0f :", i, (blk % gx) * 16 + (wv & 1) * 8, (blk / gx) * 16 + (wv >> 1) * 8, top[i].first);
-                for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", h[w * 10 + k]);
+                for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", h[w * 16 + k]);
                 fprintf(stderr, "\n");
             }
             if (const char* dump = getenv("RTX950_PROF_DUMP")) {
-                if (FILE* f = fopen(dump, "wb")) { fwrite(h.data(), 4, (size_t)129600 * 10, f); fclose(f); }
+                if (FILE* f = fopen(dump, "wb")) { fwrite(h.data(), 4, (size_t)129600 * 16, f); fclose(f); }
             }
             size_t hist[8] = {0}; for (auto& t : top) { int b = 0; double v = t.first; while (v > 8192 && b < 7) { v /= 2; ++b; } hist[b]++; }
             fprintf(stderr, "  histogram of wave cycles (<=8K,16K,32K,64K,128K,256K,512K,more):"); for (int b = 0; b < 8; ++b) fprintf(stderr, " %zu", hist[b]); fprintf(stderr, "\n");

@@ -429,7 +429,7 @@ DEV float powf_like_libm(float x, float y)
 #ifdef RTX_PROFILE
 struct Prof { uint32_t t[10]; uint32_t last; };
 __device__ Prof* g_prof_unused;
-#define PROF_DECL Prof prof; for (int k_ = 0; k_ < 10; ++k_) prof.t[k_] = 0u; prof.last = (uint32_t)__builtin_readcyclecounter();
+#define PROF_DECL Prof prof; for (int k_ = 0; k_ < 10; ++k_) prof.t[k_] = 0u; prof.last = (uint32_t)__builtin_readcyclecounter(); const uint32_t prof_t0 = prof.last; const uint32_t prof_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #define PROF_ARG , Prof& prof
 #define PROF_PASS , prof
 #define PROF_MARK(k) do { uint32_t n_ = (uint32_t)__builtin_readcyclecounter(); prof.t[k] += n_ - prof.last; prof.last = n_; } while (0)
@@ -627,11 +627,12 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
 }
 
 // ---------------------------------------------------------------- nearest hit (render.rs:87-101)
-template <int PASS, bool COUNT>
-DEV uint32_t nearest_query(const Params& P, bool active, V3 o, V3 d, Counters& cnt PROF_ARG)
+// `pass` is wave-uniform: PASS_SPHERES walks the sphere list, PASS_CUBES the cube list.
+template <bool COUNT>
+DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3 d, Counters& cnt PROF_ARG)
 {
     uint32_t best_idx = kNoHit;
-    if constexpr (PASS == PASS_CUBES) {
+    if (pass == PASS_CUBES) {
         QState st;
         st.b1 = __builtin_inff(); st.b2 = __builtin_inff(); st.i1 = kNoHit;
         st.best = __builtin_inff(); st.best_i = kNoHit; st.done = false; st.blocker = kNoHit; st.tol = 0.0f;
@@ -664,14 +665,14 @@ DEV uint32_t nearest_query(const Params& P, bool active, V3 o, V3 d, Counters& c
 // ---------------------------------------------------------------- shadow (render.rs:44-70)
 // First object in array order, among those whose id differs from the impact object's
 // (render.rs:113), whose ray_intersect returns Some.  Not the nearest one.
-template <int PASS, bool COUNT>
-DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, uint32_t impact_id, uint32_t& blocker, Counters& cnt PROF_ARG)
+template <bool COUNT>
+DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V3 light_pos, uint32_t impact_id, uint32_t& blocker, Counters& cnt PROF_ARG)
 {
     const V3 dir = vnormalize(vsub(light_pos, origin));
     blocker = kNoHit;
     float sdist = 0.0f;
     if constexpr (COUNT) cnt.shadow_rays += active ? 1u : 0u;
-    if constexpr (PASS == PASS_CUBES) {
+    if (pass == PASS_CUBES) {
         QState st;
         st.b1 = 0.0f; st.b2 = 0.0f; st.i1 = kNoHit; st.best = 0.0f; st.best_i = kNoHit;
         st.done = false; st.blocker = kNoHit; st.tol = 0.0f;
@@ -701,10 +702,10 @@ DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, ui
             const bool tested = active && !done && (load_sphere_meta_uniform(P.sphere_meta, i).id != impact_id);
             if constexpr (COUNT) cnt.sphere_tests += tested ? 1u : 0u;
             float dist = 0.0f;
-            const bool pass = sphere_exact(s, origin, dir, dist) && tested;
-            blocker = pass ? i : blocker;
-            sdist = pass ? dist : sdist;
-            done = done || pass;
+            const bool pass_i = sphere_exact(s, origin, dir, dist) && tested;
+            blocker = pass_i ? i : blocker;
+            sdist = pass_i ? dist : sdist;
+            done = done || pass_i;
             if (!wave_any(active && !done)) break;
         }
     }
@@ -715,9 +716,7 @@ DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, ui
         const V3 sp = vadd(origin, vscale(dir, sdist));
         const V3 dv = vsub(sp, light_pos);  // distance2(a,b) = norm_squared(b-a)
         const float d2 = vdot(dv, dv);
-        uint32_t bm;
-        if constexpr (PASS == PASS_CUBES) bm = P.cube_mat[bi];
-        else bm = P.sphere_meta[bi].material;
+        const uint32_t bm = (pass == PASS_CUBES) ? P.cube_mat[bi] : P.sphere_meta[bi].material;
         const float sh = sdist / d2 * (1.0f - P.mats[bm].transparency);
         shadow = has ? sh : 0.0f;
     }
@@ -725,137 +724,219 @@ DEV float shadow_query(const Params& P, bool active, V3 origin, V3 light_pos, ui
     return shadow;
 }
 
-// ---------------------------------------------------------------- cast_ray (render.rs:73-229)
-// Secondary rays are traced once per hit and reused by every light iteration; the reference
-// re-traces them per light with identical results.  Because every operand of the light fold is a
-// non-negative u8 and `+` saturates, ((acc + X) + Y) + Z == min(255, acc+X+Y+Z), so the fold
-// equals min(255, sum_l DS_l + L*(refl*k_r) + L*(refr*k_t)) per channel and can be evaluated
-// after the children return.
-//
-// Predicated form: every lane of the wave executes the call; `active` says whether the lane has a
-// ray.  Results of inactive lanes are unspecified and unused.
-template <int PASS, int DEPTH, bool DBG, bool COUNT>
-DEV Col cast_ray(const Params& P, bool active, V3 o, V3 d, float ambient, uint32_t& hash, uint32_t& hit_idx, Totals& tot PROF_ARG)
+// ---------------------------------------------------------------- the ray tree (cast_ray, render.rs:73-229)
+// The reference recurses: a hit spawns a reflection and a refraction ray per light iteration, to depth
+// 3.  Two restatements that leave every output bit unchanged:
+//  * children are traced once per hit and reused by every light iteration (the reference re-traces them
+//    with identical results).  Because every operand of the light fold is a non-negative u8 and `+`
+//    saturates, ((acc + X) + Y) + Z == min(255, acc+X+Y+Z), so the fold equals
+//    min(255, sum_l DS_l + L*(refl*k_r) + L*(refr*k_t)) per channel and is evaluated after the children
+//    return (node_finish);
+//  * the recursion is an explicit depth-first walk with ONE copy of the node code.  All 64 lanes of a
+//    wave are at the same depth at the same time (`active` says which lanes have a ray), so the walk's
+//    control state is wave-uniform and the per-lane frames live in LDS, indexed by depth.  (Unrolling
+//    the recursion by template depth, as an earlier version did, gave 110 KB of code - more than the
+//    instruction cache - and several hundred spilled registers.)
+// Frame of a node waiting for its children, per lane:
+enum { F_RO = 0, F_RD = 3, F_SUMF = 6, F_C0 = 7, F_KR = 8, F_KT = 9, F_H = 10, F_H0 = 11 };
+constexpr int kStackDepth = 3;  // nodes at depth 0..2 can wait for traced children (max_depth <= 3)
+template <bool DBG>
+constexpr int frame_words() { return DBG ? 12 : 10; }
+constexpr uint32_t kHitFlag = 1u << 24;  // in F_SUMF, above the packed 0x00RRGGBB light sum
+
+// min(255, sum + L*trunc(c_refl*k_r) + L*trunc(c_refr*k_t)) for lanes with a hit, sky otherwise
+DEV uint32_t node_finish(const Params& P, uint32_t sumf, float k_r, float k_t, uint32_t c_refl, uint32_t c_refr)
 {
-    const Col sky = col_from_hex(P.sky);
+    const Col sum = col_from_hex(sumf);
+    const Col rl = col_mul(col_from_hex(c_refl), k_r);
+    const Col rr = col_mul(col_from_hex(c_refr), k_t);
+    const float fl = (float)P.n_lights;
+    Col lit;
+    lit.r = __builtin_fminf(sum.r + fl * rl.r + fl * rr.r, 255.0f);
+    lit.g = __builtin_fminf(sum.g + fl * rl.g + fl * rr.g, 255.0f);
+    lit.b = __builtin_fminf(sum.b + fl * rl.b + fl * rr.b, 255.0f);
+    return (sumf & kHitFlag) ? col_to_hex(lit) : P.sky;
+}
+
+// One pass of render.rs:298-312 (spheres with ambient 1, or cubes with ambient_light) for the wave's
+// 64 primary rays: returns the packed colour, the primary hit index and the tree hash per lane.
+template <bool DBG, bool COUNT>
+DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d, float ambient, uint32_t* stk, uint32_t& hash, uint32_t& hit_idx,
+                        Totals& tot PROF_ARG)
+{
+    constexpr int F = frame_words<DBG>();
+    const uint32_t lane = threadIdx.x & 63u;
     hit_idx = kNoHit;
     hash = kHashCut;
-    if constexpr (DEPTH > 3) {
-        return sky;
-    } else {
-        if ((uint32_t)DEPTH > P.max_depth) return sky;  // wave-uniform
-        if (!wave_any(active)) return sky;                // wave-uniform
-        Counters cnt = {0u, 0u, 0u, 0u, 0u};
-        PROF_MARK(PH_OTHER);
-        const uint32_t idx = nearest_query<PASS, COUNT>(P, active, o, d, cnt PROF_PASS);
-        hit_idx = idx;
-        uint32_t h = hmix(kHashBasis, idx);
-        Col result = sky;
-        const bool hit_any = active && (idx != kNoHit);
-        if (wave_any(hit_any)) {
-            const uint32_t sidx = hit_any ? idx : 0u;  // lanes without a hit shade object 0 and discard the result
-            if constexpr (COUNT) cnt.shaded_hits += hit_any ? 1u : 0u;
-            Hit hit;
-            if constexpr (PASS == PASS_CUBES) hit = cube_resolve(P, sidx, o, d);
-            else hit = sphere_resolve(P, sidx, o, d);
-            const MatRec m = P.mats[hit.material];
-            PROF_MARK(PH_RESOLVE);
-
-            Col tx;
-            if (m.texture >= 0) tx = texel_of_face(P, m.texture, hit.face, hit.u * P.sprite, hit.v * P.sprite);
-            else tx = col_from_hex(m.diffuse_0rgb);
-            const Col tx_a = col_mul(tx, m.albedo0);
-            const V3 view_dir = vnormalize(vsub(o, hit.p));
-            const float k_ds = 1.0f - m.reflectivity - m.transparency;
-
+    if (!wave_any(active0)) return P.sky;
+    uint32_t depth = 0u;     // wave-uniform
+    uint32_t slotbits = 0u;  // bit k: the node waiting at depth k is tracing its second child
+    bool act = active0;
+    bool unwinding = false;
+    uint32_t res = P.sky, res_h = kHashCut;
+    for (;;) {
+        if (!unwinding) {
+            // ------------------------------------------------ one node: nearest hit, shading, child rays
+            Counters cnt = {0u, 0u, 0u, 0u, 0u};
+            PROF_MARK(PH_OTHER);
+            const uint32_t idx = nearest_query<COUNT>(P, pass, act, o, d, cnt PROF_PASS);
+            if (depth == 0u) hit_idx = idx;
+            uint32_t h = hmix(kHashBasis, idx);
+            const bool hit_any = act && (idx != kNoHit);
             Col sum = Col{0.0f, 0.0f, 0.0f};
-            const uint32_t nl = P.n_lights;
-            for (uint32_t li = 0; li < nl; ++li) {
-                const LightRec L = P.lights[li];
-                const V3 lp = v3(L.px, L.py, L.pz);
-                const V3 light_dir = vnormalize(vsub(lp, hit.p));
-                const V3 reflect_dir = vnormalize(reflect(vneg(light_dir), hit.n));
-                uint32_t blocker;
-                PROF_MARK(PH_SHADE);
-                const float shadow = shadow_query<PASS, COUNT>(P, hit_any, hit.p, lp, hit.id, blocker, cnt PROF_PASS);
-                if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
-                const float light_intensity = L.intensity * (1.0f - shadow);
-                const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
-                const Col diffuse = col_mul(col_mul(tx_a, diffuse_intensity), light_intensity);
-                const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m.specular);
-                const Col specular = col_mul(col_mul(col_mul(col_from_hex(L.color_0rgb), m.albedo1), spec_i), light_intensity);
-                sum = col_add(sum, col_mul(col_add(diffuse, specular), k_ds));
-            }
+            float k_r = 0.0f, k_t = 0.0f;
+            bool has_refl = false, has_refr = false;
+            V3 refl_o = o, refl_d = d, refr_o = o, refr_d = d;
+            if (wave_any(hit_any)) {
+                const uint32_t sidx = hit_any ? idx : 0u;  // lanes without a hit shade object 0 and discard the result
+                if constexpr (COUNT) cnt.shaded_hits += hit_any ? 1u : 0u;
+                Hit hit;
+                if (pass == PASS_CUBES) hit = cube_resolve(P, sidx, o, d);
+                else hit = sphere_resolve(P, sidx, o, d);
+                const MatRec m = P.mats[hit.material];
+                PROF_MARK(PH_RESOLVE);
 
-            PROF_MARK(PH_SHADE);
-            // children (render.rs:154-193)
-            const bool has_refl = hit_any && (m.reflectivity > 0.0f);
-            const bool has_refr = hit_any && (m.transparency > 0.0f);
-            Col c_refl = Col{0.0f, 0.0f, 0.0f}, c_refr = Col{0.0f, 0.0f, 0.0f};
-            uint32_t h_refl = 0u, h_refr = 0u;
-            if (wave_any(has_refl || has_refr)) {
-                const V3 refl_d = vnormalize(reflect(vneg(d), hit.n));
-                const V3 refl_o = vadd(hit.p, vscale(hit.n, 1e-2f));
-                const V3 refr_d = refract(d, hit.n, m.ior);
-                const V3 refr_o = vadd(hit.p, vscale(hit.n, 1e-3f));
-                const int n_child = (has_refl ? 1 : 0) + (has_refr ? 1 : 0);
-                // slot 0 = the lane's first pending child, slot 1 = its second: lanes whose only
-                // child is a refraction trace it together with other lanes' reflections.
-                for (int slot = 0; slot < 2; ++slot) {
-                    const bool child = slot < n_child;
-                    if (!wave_any(child)) break;
-                    const bool is_refl = (slot == 0) && has_refl;
-                    const V3 co = is_refl ? refl_o : refr_o;
-                    const V3 cd = is_refl ? refl_d : refr_d;
-                    uint32_t ch, cidx;
-                    PROF_MARK(PH_CHILDSETUP);
-                    const Col cc = cast_ray<PASS, DEPTH + 1, DBG, COUNT>(P, child, co, cd, ambient, ch, cidx, tot PROF_PASS);
-                    if (child && is_refl) { c_refl = cc; h_refl = ch; }
-                    if (child && !is_refl) { c_refr = cc; h_refr = ch; }
+                Col tx;
+                if (m.texture >= 0) tx = texel_of_face(P, m.texture, hit.face, hit.u * P.sprite, hit.v * P.sprite);
+                else tx = col_from_hex(m.diffuse_0rgb);
+                const Col tx_a = col_mul(tx, m.albedo0);
+                const V3 view_dir = vnormalize(vsub(o, hit.p));
+                const float k_ds = 1.0f - m.reflectivity - m.transparency;
+
+                const uint32_t nl = P.n_lights;
+                for (uint32_t li = 0; li < nl; ++li) {
+                    const LightRec L = P.lights[li];
+                    const V3 lp = v3(L.px, L.py, L.pz);
+                    const V3 light_dir = vnormalize(vsub(lp, hit.p));
+                    const V3 reflect_dir = vnormalize(reflect(vneg(light_dir), hit.n));
+                    uint32_t blocker;
+                    PROF_MARK(PH_SHADE);
+                    const float shadow = shadow_query<COUNT>(P, pass, hit_any, hit.p, lp, hit.id, blocker, cnt PROF_PASS);
+                    if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
+                    const float light_intensity = L.intensity * (1.0f - shadow);
+                    const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
+                    const Col diffuse = col_mul(col_mul(tx_a, diffuse_intensity), light_intensity);
+                    const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m.specular);
+                    const Col specular = col_mul(col_mul(col_mul(col_from_hex(L.color_0rgb), m.albedo1), spec_i), light_intensity);
+                    sum = col_add(sum, col_mul(col_add(diffuse, specular), k_ds));
                 }
+                PROF_MARK(PH_SHADE);
+                // children (render.rs:154-193)
+                k_r = m.reflectivity;
+                k_t = m.transparency;
+                has_refl = hit_any && (k_r > 0.0f);
+                has_refr = hit_any && (k_t > 0.0f);
+                if (wave_any(has_refl || has_refr)) {
+                    refl_d = vnormalize(reflect(vneg(d), hit.n));
+                    refl_o = vadd(hit.p, vscale(hit.n, 1e-2f));
+                    refr_d = refract(d, hit.n, m.ior);
+                    refr_o = vadd(hit.p, vscale(hit.n, 1e-3f));
+                }
+                PROF_MARK(PH_CHILDSETUP);
             }
-            const Col rl = col_mul(c_refl, m.reflectivity);
-            const Col rr = col_mul(c_refr, m.transparency);
-            const float fl = (float)nl;
-            Col lit;
-            lit.r = __builtin_fminf(sum.r + fl * rl.r + fl * rr.r, 255.0f);
-            lit.g = __builtin_fminf(sum.g + fl * rl.g + fl * rr.g, 255.0f);
-            lit.b = __builtin_fminf(sum.b + fl * rl.b + fl * rr.b, 255.0f);
-            result.r = hit_any ? lit.r : sky.r;
-            result.g = hit_any ? lit.g : sky.g;
-            result.b = hit_any ? lit.b : sky.b;
+            if constexpr (COUNT) {
+                unsigned long long w = 1ull;  // n_lights^depth: how often the reference runs this node
+                for (uint32_t k = 0; k < depth; ++k) w *= P.n_lights;
+                totals_add(tot, cnt, w);
+            }
+            const uint32_t sumf = col_to_hex(sum) | (hit_any ? kHitFlag : 0u);
+            const bool any_child = has_refl || has_refr;
+            if (depth < P.max_depth && wave_any(any_child)) {
+                // wait for the children: the lane's first child is its reflection if it has one, else its
+                // refraction; lanes with both trace the refraction in a second round (slot 1)
+                uint32_t* fr = stk + (depth * F) * 64u + lane;
+                fr[(F_RO + 0) * 64] = __builtin_bit_cast(uint32_t, refr_o.x);
+                fr[(F_RO + 1) * 64] = __builtin_bit_cast(uint32_t, refr_o.y);
+                fr[(F_RO + 2) * 64] = __builtin_bit_cast(uint32_t, refr_o.z);
+                fr[(F_RD + 0) * 64] = __builtin_bit_cast(uint32_t, refr_d.x);
+                fr[(F_RD + 1) * 64] = __builtin_bit_cast(uint32_t, refr_d.y);
+                fr[(F_RD + 2) * 64] = __builtin_bit_cast(uint32_t, refr_d.z);
+                fr[F_SUMF * 64] = sumf;
+                fr[F_KR * 64] = __builtin_bit_cast(uint32_t, k_r);
+                fr[F_KT * 64] = __builtin_bit_cast(uint32_t, k_t);
+                if constexpr (DBG) fr[F_H * 64] = h;
+                o = has_refl ? refl_o : refr_o;
+                d = has_refl ? refl_d : refr_d;
+                act = any_child;
+                slotbits &= ~(1u << depth);
+                depth += 1u;
+                continue;
+            }
+            // children beyond max_depth return the sky colour without tracing (render.rs:80-82)
+            const uint32_t zero = 0u;
+            res = node_finish(P, sumf, k_r, k_t, has_refl ? P.sky : zero, has_refr ? P.sky : zero);
+            if constexpr (DBG) res_h = hit_any ? hmix(hmix(h, has_refl ? kHashCut : 0u), has_refr ? kHashCut : 0u) : h;
+            unwinding = true;
+        }
+        // ---------------------------------------------------- hand (res, res_h) to the waiting parent
+        if (depth == 0u) break;
+        depth -= 1u;
+        PROF_MARK(PH_OTHER);
+        uint32_t* fr = stk + (depth * F) * 64u + lane;
+        const uint32_t sumf = fr[F_SUMF * 64];
+        const float k_r = __builtin_bit_cast(float, fr[F_KR * 64]);
+        const float k_t = __builtin_bit_cast(float, fr[F_KT * 64]);
+        const bool hit_any = (sumf & kHitFlag) != 0u;
+        const bool has_refl = hit_any && (k_r > 0.0f);
+        const bool has_refr = hit_any && (k_t > 0.0f);
+        uint32_t c0, c1 = 0u, h0 = 0u, h1 = 0u;
+        if (((slotbits >> depth) & 1u) == 0u) {
+            c0 = res;
+            if constexpr (DBG) h0 = res_h;
+            if (wave_any(has_refl && has_refr)) {
+                fr[F_C0 * 64] = c0;
+                if constexpr (DBG) fr[F_H0 * 64] = h0;
+                o = v3(__builtin_bit_cast(float, fr[(F_RO + 0) * 64]), __builtin_bit_cast(float, fr[(F_RO + 1) * 64]),
+                       __builtin_bit_cast(float, fr[(F_RO + 2) * 64]));
+                d = v3(__builtin_bit_cast(float, fr[(F_RD + 0) * 64]), __builtin_bit_cast(float, fr[(F_RD + 1) * 64]),
+                       __builtin_bit_cast(float, fr[(F_RD + 2) * 64]));
+                act = has_refl && has_refr;
+                slotbits |= 1u << depth;
+                depth += 1u;
+                unwinding = false;
+                continue;
+            }
+        } else {
+            c0 = fr[F_C0 * 64];
+            c1 = res;
             if constexpr (DBG) {
-                const uint32_t hh = hmix(hmix(h, h_refl), h_refr);
-                h = hit_any ? hh : h;
+                h0 = fr[F_H0 * 64];
+                h1 = res_h;
             }
         }
-        if constexpr (COUNT) {
-            unsigned long long w = 1ull;  // n_lights^DEPTH: how often the reference runs this node
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) w *= P.n_lights;
-            totals_add(tot, cnt, w);
+        const uint32_t zero = 0u;
+        const uint32_t c_refl = has_refl ? c0 : zero;
+        const uint32_t c_refr = has_refr ? (has_refl ? c1 : c0) : zero;
+        res = node_finish(P, sumf, k_r, k_t, c_refl, c_refr);
+        if constexpr (DBG) {
+            const uint32_t h = fr[F_H * 64];
+            const uint32_t h_refl = has_refl ? h0 : 0u;
+            const uint32_t h_refr = has_refr ? (has_refl ? h1 : h0) : 0u;
+            res_h = hit_any ? hmix(hmix(h, h_refl), h_refr) : h;
         }
-        hash = h;
-        return result;
     }
+    hash = res_h;
+    return res;
 }
 
 // ---------------------------------------------------------------- render (render.rs:234-324)
-// One lane per pixel; a wave covers an 8x8 pixel tile (coherent rays -> tight wave-level bounds in
-// the cull), a 256-thread workgroup covers 16x16 pixels.
-#ifndef RTX_MIN_WAVES
-#define RTX_MIN_WAVES 4
+// One lane per pixel; a wave (= one workgroup) covers an 8x8 pixel tile: coherent rays give tight
+// wave-level bounds in the cull, and single-wave workgroups retire independently (a 16x16 tile of 4
+// waves holds its 4 slots until the slowest wave is done: measured 20 % of the slots idle).
+#ifndef RTX_WAVES_PER_EU
+#define RTX_WAVES_PER_EU 4
 #endif
 template <bool DBG, bool COUNT>
-__global__ __launch_bounds__(256, RTX_MIN_WAVES) void render_kernel(const Params P)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PER_EU, RTX_WAVES_PER_EU))) void render_kernel(const Params P)
 {
+    __shared__ uint32_t stk[kStackDepth * frame_words<DBG>() * 64];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t ly = (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t x = blockIdx.x * 8u + (lane & 7u);
+    const uint32_t ly = (blockIdx.y & 1u) * 8u + (lane >> 3);
     // interleaved parts: this launch renders 16-row blocks part, part+n_parts, ... of [y0,y1)
-    const uint32_t y = P.y0 + (blockIdx.y * P.n_parts + P.part) * kRowBlock + ly;
-    const uint32_t out_row = blockIdx.y * kRowBlock + ly;
+    const uint32_t blk = blockIdx.y >> 1;
+    const uint32_t y = P.y0 + (blk * P.n_parts + P.part) * kRowBlock + ly;
+    const uint32_t out_row = blk * kRowBlock + ly;
     Totals cnt;
 #pragma unroll
     for (int k = 0; k < 10; ++k) cnt.v[k] = 0ull;
@@ -875,13 +956,17 @@ __global__ __launch_bounds__(256, RTX_MIN_WAVES) void render_kernel(const Params
     const V3 dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));
     const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
 
-    uint32_t hs, hc, hit_s, hit_c;
     PROF_MARK(PH_RAYGEN);
-    const Col cs = cast_ray<PASS_SPHERES, 0, DBG, COUNT>(P, active, eye, dir, 1.0f, hs, hit_s, cnt PROF_PASS);
-    const Col cc = cast_ray<PASS_CUBES, 0, DBG, COUNT>(P, active, eye, dir, P.ambient, hc, hit_c, cnt PROF_PASS);
+    // render.rs:298-312: a spheres-only pass with ambient 1, a cubes-only pass with ambient_light; the
+    // sphere colour wins unless it equals the sky colour
+    uint32_t px = 0u, hs = 0u, hc = 0u, hit_s = kNoHit, hit_c = kNoHit;
+    for (uint32_t pass = PASS_SPHERES; pass <= PASS_CUBES; ++pass) {
+        uint32_t hh, hi;
+        const uint32_t c = trace_tree<DBG, COUNT>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
+        if (pass == PASS_SPHERES) { px = c; hs = hh; hit_s = hi; }
+        else { px = (px == P.sky) ? c : px; hc = hh; hit_c = hi; }
+    }
     PROF_MARK(PH_OTHER);
-    const uint32_t s_hex = col_to_hex(cs);
-    uint32_t px = (s_hex == P.sky) ? col_to_hex(cc) : s_hex;  // render.rs:308-312
     const size_t i_frame = (size_t)y * P.width + x;
     if (i_frame == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
     const size_t i_band = (size_t)out_row * P.width + x;
@@ -898,9 +983,15 @@ __global__ __launch_bounds__(256, RTX_MIN_WAVES) void render_kernel(const Params
 #ifdef RTX_PROFILE
     PROF_MARK(PH_OTHER);
     if (lane == 0u && P.counters) {
-        // per-wave slots (no atomics: contended atomics would dominate the run); the host sums them
-        uint32_t* slot = (uint32_t*)P.counters + 64 + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave) * 10u;
+        // per-wave slots (no atomics: contended atomics would dominate the run); the host reads them
+        uint32_t* slot = (uint32_t*)P.counters + 64 + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16u;
         for (int k = 0; k < 10; ++k) slot[k] = prof.t[k];
+        slot[10] = prof_t0;
+        slot[11] = prof.last;
+        slot[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave/simd/cu/sh/se
+        slot[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+        slot[14] = prof_r0;
+        slot[15] = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz, common to the chip
     }
 #endif
     if constexpr (COUNT) {
@@ -924,8 +1015,8 @@ int launch_render(const Params& p, int variant, void* stream)
     if (p.n_parts == 0u || p.part >= p.n_parts) return (int)hipErrorInvalidValue;
     if (p.part >= blocks) return (int)hipSuccess;  // this part owns no rows
     const uint32_t my_blocks = (blocks - p.part + p.n_parts - 1u) / p.n_parts;
-    dim3 grid((p.width + 15u) / 16u, my_blocks, 1u);
-    dim3 block(256u, 1u, 1u);
+    dim3 grid((p.width + 7u) / 8u, my_blocks * 2u, 1u);  // one 8x8 tile per single-wave workgroup
+    dim3 block(64u, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
     case kVariantDebug: hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, s, p); break;
