@@ -42,6 +42,10 @@ struct rt_ctx {
     uint32_t* d_dbg[3] = {nullptr, nullptr, nullptr};
     size_t dbg_capacity[3] = {0, 0, 0};
     unsigned long long* d_counters = nullptr;
+    // per-frame tile stamps (classify_tiles)
+    uint32_t* d_stamps = nullptr;
+    size_t stamps_cap = 0;  // in words
+    uint32_t frame_id = 0;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded pairs since last query
@@ -184,6 +188,59 @@ int ensure(rt_ctx* ctx, uint32_t** buf, size_t* cap, size_t need)
     return RT_OK;
 }
 
+// Stamps the tiles that some cube's projection touches (classify_tiles) and points `p` at them.  On
+// anything irregular (non-finite camera, skewed basis, non-finite bounds) p.tile_stamps stays null and
+// every tile is traced.
+int classify(rt_ctx* ctx, Params& p)
+{
+    p.tile_stamps = nullptr;
+    p.tiles_x = (p.width + 7u) / 8u;
+    p.tiles_y = (p.height + 7u) / 8u;
+    p.frame_id = 0u;
+    TileParams t;
+    std::memset(&t, 0, sizeof(t));
+    double mag = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        t.eye[k] = p.eye[k]; t.right[k] = p.right[k]; t.up[k] = p.up[k]; t.fwd[k] = p.fwd[k];
+        if (!std::isfinite(t.eye[k]) || !std::isfinite(t.right[k]) || !std::isfinite(t.up[k]) || !std::isfinite(t.fwd[k])) return RT_OK;
+        mag = std::max(mag, std::fabs(t.eye[k]));
+    }
+    if (!std::isfinite(p.bound_max)) return RT_OK;
+    mag = std::max(mag, (double)p.bound_max);
+    const double* r = t.right; const double* u = t.up; const double* f = t.fwd;
+    const double det = r[0] * (u[1] * f[2] - u[2] * f[1]) - r[1] * (u[0] * f[2] - u[2] * f[0]) + r[2] * (u[0] * f[1] - u[1] * f[0]);
+    if (!(std::fabs(det) > 0.5 && std::fabs(det) < 2.0)) return RT_OK;  // an orthonormal basis has |det| = 1
+    const size_t words = kStampBase + (size_t)p.tiles_x * p.tiles_y;
+    if (ctx->stamps_cap < words) {
+        if (ctx->d_stamps) HIP_TRY(ctx, hipFree(ctx->d_stamps));
+        ctx->d_stamps = nullptr;
+        ctx->stamps_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_stamps, words * sizeof(uint32_t)));
+        ctx->stamps_cap = words;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_stamps, 0, words * sizeof(uint32_t), ctx->stream));
+        ctx->frame_id = 0u;
+    }
+    if (++ctx->frame_id == 0u) {  // wrapped: stale stamps could alias, start over
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_stamps, 0, ctx->stamps_cap * sizeof(uint32_t), ctx->stream));
+        ctx->frame_id = 1u;
+    }
+    t.cube_filt = p.cube_filt;
+    t.n_cubes = p.n_cubes;
+    t.inv_det = 1.0 / det;
+    t.pad = mag * 0x1p-17;  // >= 64 ulp of the largest coordinate involved
+    t.aspect = (double)((float)p.width / (float)p.height);
+    t.width = p.width; t.height = p.height; t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y;
+    t.stamps = ctx->d_stamps;
+    t.frame_id = ctx->frame_id;
+    if (p.n_cubes > 0u) {
+        hipError_t e = (hipError_t)launch_classify(t, (void*)ctx->stream);
+        if (e != hipSuccess) return fail_hip(ctx, e, "classify kernel launch");
+    }
+    p.tile_stamps = ctx->d_stamps;
+    p.frame_id = ctx->frame_id;
+    return RT_OK;
+}
+
 int launch_timed(rt_ctx* ctx, const Params& p, int variant)
 {
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -247,6 +304,7 @@ int rt_ctx_destroy(rt_ctx* ctx)
     (void)hipFree(ctx->d_fb);
     for (auto& b : ctx->d_dbg) (void)hipFree(b);
     (void)hipFree(ctx->d_counters);
+    (void)hipFree(ctx->d_stamps);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(ctx->stream);
@@ -391,6 +449,7 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
 #ifdef RTX_PROFILE
     p.counters = ctx->d_counters;
 #endif
+    if ((rc = classify(ctx, p)) != RT_OK) return rc;
     int variant = kVariantRender;
     if (dbg_device && (dbg_device->hit_cube || dbg_device->hit_sphere || dbg_device->tree_hash)) {
         p.hit_cube = dbg_device->hit_cube;
@@ -455,6 +514,7 @@ int rt_count_rays_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     p.n_parts = n_parts;
     p.part = part;
     p.counters = ctx->d_counters;
+    if ((rc = classify(ctx, p)) != RT_OK) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
     hipError_t e = (hipError_t)launch_render(p, kVariantCount, (void*)ctx->stream);
     if (e != hipSuccess) return fail_hip(ctx, e, "count kernel launch");
@@ -509,10 +569,10 @@ int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches)
             std::vector<std::pair<double, size_t>> top;
             for (size_t w = 0; w < kProfWaves; ++w) { double t = 0; for (int k = 0; k < 10; ++k) t += h[w * 16 + k]; if (t > 0) top.push_back({t, w}); }
             std::sort(top.begin(), top.end()); std::reverse(top.begin(), top.end());
-            const size_t gx = 240;  // 3840/16 (diagnostic assumes the 4K bench frame)
+            const size_t gx = 480;  // 3840/8 (diagnostic assumes the 4K bench frame)
             for (size_t i = 0; i < top.size() && i < 12; ++i) {
-                size_t w = top[i].second, blk = w / 4, wv = w % 4;
-                fprintf(stderr, "  slow wave %zu: tile x=%zu y=%zu cyc=%.0f :", i, (blk % gx) * 16 + (wv & 1) * 8, (blk / gx) * 16 + (wv >> 1) * 8, top[i].first);
+                size_t w = top[i].second;
+                fprintf(stderr, "  slow wave %zu: tile x=%zu y=%zu cyc=%.0f :", i, (w % gx) * 8, (w / gx) * 8, top[i].first);
                 for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", h[w * 16 + k]);
                 fprintf(stderr, "\n");
             }

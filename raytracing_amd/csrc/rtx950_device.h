@@ -72,6 +72,12 @@ struct Params {
     float eye[3], right[3], up[3], fwd[3];  // camera basis, reference src/camera.rs:34-36 (hoisted)
     uint32_t width, height, y0, y1;
     uint32_t n_parts, part;  // 16-row blocks b with b % n_parts == part are rendered, output compact
+    // Tile stamps written by classify_tiles for this frame (null: every tile is traced).  Word 0 ==
+    // frame_id: some cube could not be projected, trace every tile; word 64 + ty*tiles_x + tx ==
+    // frame_id: some cube's padded projection touches the 8x8 pixel tile (tx, ty) of the frame.
+    const uint32_t* tile_stamps;
+    uint32_t tiles_x, tiles_y;
+    uint32_t frame_id;
     float ambient;
     uint32_t sky;
     uint32_t max_depth;
@@ -85,10 +91,27 @@ struct Params {
     unsigned long long* counters;  // 10 x u64, rt_counters order
 };
 
+// classify_tiles: one wave per cube projects the cube's padded corners through the frame's camera and
+// stamps the 8x8 pixel tiles its bounding rectangle touches.  Primary rays of unstamped tiles cannot
+// meet any cube (see the kernel's comment), so render_kernel answers their cube pass without tracing.
+struct TileParams {
+    const float* cube_filt;  // (centre.xyz, half size) per cube
+    uint32_t n_cubes;
+    double eye[3], right[3], up[3], fwd[3];
+    double inv_det;          // 1 / det[right up fwd]
+    double pad;              // absolute padding of every cube bound
+    double aspect;           // (f32) width / height, as the kernel computes it
+    uint32_t width, height, tiles_x, tiles_y;
+    uint32_t* stamps;
+    uint32_t frame_id;
+};
+constexpr uint32_t kStampBase = 64;  // first per-tile word
+
 enum KernelVariant { kVariantRender = 0, kVariantDebug = 1, kVariantCount = 2 };
 
 // Launches the render kernel for rows [y0,y1) on `stream` (hipStream_t passed as void*).
 // Returns a hipError_t as int.
 int launch_render(const Params& p, int variant, void* stream);
+int launch_classify(const TileParams& t, void* stream);
 
 }  // namespace rtx950

@@ -957,12 +957,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
     const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
 
     PROF_MARK(PH_RAYGEN);
+#if defined(RTX_EXP) && RTX_EXP == 1
+    if constexpr (!DBG && !COUNT) {
+        if (active && P.out) P.out[(size_t)out_row * P.width + x] = __builtin_bit_cast(uint32_t, dir.x + dir.y + dir.z + eye.x);
+        return;
+    }
+#elif defined(RTX_EXP) && RTX_EXP == 0
+    if constexpr (!DBG && !COUNT) {
+        if (active && P.out) P.out[(size_t)out_row * P.width + x] = x + y;
+        return;
+    }
+#endif
     // render.rs:298-312: a spheres-only pass with ambient 1, a cubes-only pass with ambient_light; the
     // sphere colour wins unless it equals the sky colour
     uint32_t px = 0u, hs = 0u, hc = 0u, hit_s = kNoHit, hit_c = kNoHit;
+    // Passes that cannot hit anything are not traced (wave-uniform): no spheres at all, or an 8x8 tile
+    // that no cube's projection touches (classify_tiles).  The render tile is aligned to the band
+    // start y0, so it can straddle two rows of the frame-aligned classification tiles.
+    bool no_cubes = false;
+    if (P.tile_stamps) {
+        const uint32_t ty0 = P.y0 + (blk * P.n_parts + P.part) * kRowBlock + (blockIdx.y & 1u) * 8u;
+        const uint32_t last = P.tiles_y - 1u;
+        const uint32_t r0 = (ty0 >> 3) < last ? (ty0 >> 3) : last;
+        const uint32_t r1 = ((ty0 + 7u) >> 3) < last ? ((ty0 + 7u) >> 3) : last;
+        KCONST uint32_t* st = (KCONST uint32_t*)P.tile_stamps;
+        const uint32_t s_all = st[0], s0 = st[kStampBase + r0 * P.tiles_x + blockIdx.x], s1 = st[kStampBase + r1 * P.tiles_x + blockIdx.x];
+        no_cubes = (s_all != P.frame_id) && (s0 != P.frame_id) && (s1 != P.frame_id);
+    }
     for (uint32_t pass = PASS_SPHERES; pass <= PASS_CUBES; ++pass) {
-        uint32_t hh, hi;
-        const uint32_t c = trace_tree<DBG, COUNT>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
+        uint32_t hh, hi, c;
+        const bool skip = (pass == PASS_SPHERES) ? (P.n_spheres == 0u) : no_cubes;
+        if (skip) {
+            c = P.sky;
+            hi = kNoHit;
+            hh = hmix(kHashBasis, kNoHit);
+            if constexpr (COUNT) {  // the reference still walks the list for this ray
+                const unsigned long long one = active ? 1ull : 0ull, tests = (pass == PASS_CUBES && active) ? P.n_cubes : 0ull;
+                cnt.v[0] += one; cnt.v[5] += one;
+                cnt.v[2] += tests; cnt.v[7] += tests;
+            }
+        } else {
+            c = trace_tree<DBG, COUNT>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
+        }
         if (pass == PASS_SPHERES) { px = c; hs = hh; hit_s = hi; }
         else { px = (px == P.sky) ? c : px; hc = hh; hit_c = hi; }
     }
@@ -1006,7 +1042,69 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
     }
 }
 
+// ---------------------------------------------------------------- classify_tiles
+// Which 8x8 pixel tiles can contain a primary ray that meets a cube?  A pixel's ray is the line
+// eye + t (sx right + sy up + fwd) with sx = (2x/W - 1) W/H, sy = 1 - 2y/H (render.rs:245-262,
+// camera.rs:38-40).  The reference's slab test has no t < 0 rejection (cube.rs:90-145): it is a LINE
+// test, so the projection argument needs the whole (padded) cube in front of the eye; a cube with a
+// corner beside or behind it sets the trace-everything flag instead.  In exact arithmetic the line
+// meets the cube only if (sx, sy) lies in the convex hull of the projected corners, hence inside
+// their bounding rectangle.  The reference's f32 arithmetic can move a silhouette by a few ulp of
+// the coordinates involved; every bound is padded by 64 ulp of the largest coordinate (host: pad)
+// and the rectangle by two pixels.  f64 throughout; one wave per cube, lanes 0..7 = the corners.
+__global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
+{
+    const uint32_t cube = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (cube >= T.n_cubes) return;
+    const float* rec = T.cube_filt + (size_t)cube * 4u;
+    const double h = __builtin_fabs((double)rec[3]) + T.pad;
+    double q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = (double)rec[k] + (((lane >> k) & 1u) ? h : -h) - T.eye[k];
+    const double* r = T.right; const double* u = T.up; const double* f = T.fwd;
+    // q = a right + b up + c fwd (Cramer)
+    const double a = (q[0] * (u[1] * f[2] - u[2] * f[1]) - q[1] * (u[0] * f[2] - u[2] * f[0]) + q[2] * (u[0] * f[1] - u[1] * f[0])) * T.inv_det;
+    const double b = (r[0] * (q[1] * f[2] - q[2] * f[1]) - r[1] * (q[0] * f[2] - q[2] * f[0]) + r[2] * (q[0] * f[1] - q[1] * f[0])) * T.inv_det;
+    const double c = (r[0] * (u[1] * q[2] - u[2] * q[1]) - r[1] * (u[0] * q[2] - u[2] * q[0]) + r[2] * (u[0] * q[1] - u[1] * q[0])) * T.inv_det;
+    const double len = __builtin_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    double px = ((a / c) / T.aspect + 1.0) * (double)T.width * 0.5;
+    double py = (1.0 - b / c) * (double)T.height * 0.5;
+    // negated compares: NaN anywhere counts as "cannot project"
+    bool bad = !(c > 1e-3 * len) || !(c > 16.0 * T.pad) || !(__builtin_fabs(px) < 1e9) || !(__builtin_fabs(py) < 1e9);
+    double x0 = px, x1 = px, y0 = py, y1 = py;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+        x0 = __builtin_fmin(x0, __shfl_xor(x0, m, 64)); x1 = __builtin_fmax(x1, __shfl_xor(x1, m, 64));
+        y0 = __builtin_fmin(y0, __shfl_xor(y0, m, 64)); y1 = __builtin_fmax(y1, __shfl_xor(y1, m, 64));
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+        if (lane == 0u) T.stamps[0] = T.frame_id;
+        return;
+    }
+    // pixel rectangle, padded, clipped to the frame; empty -> nothing to stamp
+    const double fx0 = __builtin_floor(x0) - 2.0, fx1 = __builtin_ceil(x1) + 2.0;
+    const double fy0 = __builtin_floor(y0) - 2.0, fy1 = __builtin_ceil(y1) + 2.0;
+    if (fx1 < 0.0 || fy1 < 0.0 || fx0 > (double)T.width - 1.0 || fy0 > (double)T.height - 1.0) return;
+    const uint32_t px0 = fx0 < 0.0 ? 0u : (uint32_t)fx0, py0 = fy0 < 0.0 ? 0u : (uint32_t)fy0;
+    const uint32_t px1 = fx1 > (double)T.width - 1.0 ? T.width - 1u : (uint32_t)fx1;
+    const uint32_t py1 = fy1 > (double)T.height - 1.0 ? T.height - 1u : (uint32_t)fy1;
+    const uint32_t tx0 = px0 >> 3, tx1 = px1 >> 3, ty0 = py0 >> 3, ty1 = py1 >> 3;  // < tiles_x, < tiles_y
+    const uint32_t nx = tx1 - tx0 + 1u, n = nx * (ty1 - ty0 + 1u);
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t tx = tx0 + i % nx, ty = ty0 + i / nx;
+        T.stamps[kStampBase + (size_t)ty * T.tiles_x + tx] = T.frame_id;
+    }
+}
+
 }  // namespace
+
+int launch_classify(const TileParams& t, void* stream)
+{
+    if (t.n_cubes == 0u) return (int)hipSuccess;
+    hipLaunchKernelGGL(classify_tiles, dim3(t.n_cubes, 1u, 1u), dim3(64u, 1u, 1u), 0, (hipStream_t)stream, t);
+    return (int)hipGetLastError();
+}
 
 int launch_render(const Params& p, int variant, void* stream)
 {
