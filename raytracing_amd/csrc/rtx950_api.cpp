@@ -363,7 +363,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
         r.size = cubes[i].size;
         hcm[i] = cubes[i].material;
         hf[4 * i + 0] = cubes[i].center.x; hf[4 * i + 1] = cubes[i].center.y; hf[4 * i + 2] = cubes[i].center.z;
-        hf[4 * i + 3] = half;
+        hf[4 * i + 3] = std::fabs(half);  // min > max (negative size) is the same box to the slab test (lib.rs:29-35 sorts the two t)
         hid[i] = cubes[i].id;
         check_bound(r.minx); check_bound(r.maxx); check_bound(r.miny);
         check_bound(r.maxy); check_bound(r.minz); check_bound(r.maxz);

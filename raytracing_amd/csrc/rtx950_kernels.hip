@@ -170,6 +170,8 @@ struct RayPre {
     float tol;                // 2E: decision threshold of the two-sided filter (+inf for unsafe rays)
     float err;                // E: bound on |approximate - reference| for tmin, tmax and the distance
     bool unsafe;              // outside the ranges the error analysis assumes: always evaluated exactly
+    uint32_t zbits;           // safe rays only: bit c set = direction component c is exactly zero
+    float zdelta;             // margin of zero_axis_check
     bool wild;                // non-finite or huge components: even the wave-level cull keeps every cube
 };
 
@@ -187,31 +189,58 @@ DEV bool org_ok(float v)
 DEV RayPre ray_pre(const Params& P, V3 o, V3 d)
 {
     RayPre q;
-    const bool safe = (P.fast_ok != 0u) && dir_ok(d.x) && dir_ok(d.y) && dir_ok(d.z) && org_ok(o.x) && org_ok(o.y) && org_ok(o.z);
+    // A direction component that is exactly +-0 (the image's centre column/row, axis-parallel
+    // reflections) is handled apart: the reference's two t of that axis are +-inf (cube.rs:90-109), so
+    // the axis either does not constrain the interval (origin strictly inside the slab) or makes the
+    // staged compares fail (strictly outside).  The filter takes "does not constrain" (r = c = 0,
+    // a = 2^120: near = -huge, far = +huge) and cube_query decides inside / outside / too close to call
+    // from |k - o| against h -+ zdelta (zero_axis_check).
+    const bool zx = (d.x == 0.0f), zy = (d.y == 0.0f), zz = (d.z == 0.0f);
+    const bool safe = (P.fast_ok != 0u) && (dir_ok(d.x) || zx) && (dir_ok(d.y) || zy) && (dir_ok(d.z) || zz) && !(zx && zy && zz) &&
+                      org_ok(o.x) && org_ok(o.y) && org_ok(o.z);
     // v_rcp_f32: 1 ulp (2u relative) instead of the correctly rounded quotient; the bound below budgets for it
-    const float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
-    const float ax = __builtin_fabsf(rx), ay = __builtin_fabsf(ry), az = __builtin_fabsf(rz);
+    const float big = 0x1p120f;
+    const float rx = zx ? 0.0f : __builtin_amdgcn_rcpf(d.x), ry = zy ? 0.0f : __builtin_amdgcn_rcpf(d.y), rz = zz ? 0.0f : __builtin_amdgcn_rcpf(d.z);
+    const float ax = zx ? big : __builtin_fabsf(rx), ay = zy ? big : __builtin_fabsf(ry), az = zz ? big : __builtin_fabsf(rz);
     q.r_xy = f32x2{rx, ry};
     q.c_xy = f32x2{-(o.x * rx), -(o.y * ry)};
     q.na_xy = f32x2{-ax, -ay};
     q.rc_z = f32x2{rz, -(o.z * rz)};
     q.a_z_pm = f32x2{-az, az};
-    const float ex = (P.bound_max + __builtin_fabsf(o.x)) * ax;
-    const float ey = (P.bound_max + __builtin_fabsf(o.y)) * ay;
-    const float ez = (P.bound_max + __builtin_fabsf(o.z)) * az;
+    const float ex = zx ? 0.0f : (P.bound_max + __builtin_fabsf(o.x)) * ax;
+    const float ey = zy ? 0.0f : (P.bound_max + __builtin_fabsf(o.y)) * ay;
+    const float ez = zz ? 0.0f : (P.bound_max + __builtin_fabsf(o.z)) * az;
     q.tol = safe ? 0x1p-19f * __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) : __builtin_inff();
     q.err = 0.5f * q.tol;
     q.unsafe = !safe;
+    q.zbits = safe ? ((zx ? 1u : 0u) | (zy ? 2u : 0u) | (zz ? 4u : 0u)) : 0u;
+    const float bigo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+    // 2^-20 (B + |o|) = 16 ulp of the largest magnitude involved: RN(k -+ h), RN(k - o) and the
+    // reference's RN(bound - o) each err by at most one
+    q.zdelta = 0x1p-20f * (P.bound_max + bigo);
     // The cull (cull_test) has no division, so zero or tiny direction components are fine there: a ray
     // whose exact line misses a box by the slack margin is rejected by the reference too, also through
     // its +-inf arithmetic (cube.rs:90-113 with d_c = 0: both t of that axis are the same infinity, and
     // one of the staged compares fires).  Only non-finite or huge inputs need the keep-everything path
     // (a NaN ray passes every slab compare of the reference, which matters for shadows).
-    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
-    const float bigo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+    const float bigd = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
     const bool finite = (d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (o.x == o.x) && (o.y == o.y) && (o.z == o.z);
-    q.wild = !(finite && big <= 0x1p40f && bigo <= 0x1p20f) || (P.fast_ok == 0u);
+    q.wild = !(finite && bigd <= 0x1p40f && bigo <= 0x1p20f) || (P.fast_ok == 0u);
     return q;
+}
+
+// Zero direction components of a safe ray against cube (k, h).  miss: the origin is outside the slab
+// of such an axis by more than zdelta, so the reference's slab test fails (both t are the same
+// infinity).  unsure: within zdelta of a slab face (includes h <= zdelta): evaluate exactly.
+// Otherwise the origin is strictly inside every such slab and the axis does not constrain.
+DEV void zero_axis_check(const RayPre& q, V3 o, float kx, float ky, float kz, float h, bool& miss, bool& unsure)
+{
+    const float sx = __builtin_fabsf(kx - o.x), sy = __builtin_fabsf(ky - o.y), sz = __builtin_fabsf(kz - o.z);
+    const float hin = h - q.zdelta, hout = h + q.zdelta;
+    const bool zx = (q.zbits & 1u) != 0u, zy = (q.zbits & 2u) != 0u, zz = (q.zbits & 4u) != 0u;
+    miss = (zx && sx > hout) || (zy && sy > hout) || (zz && sz > hout);
+    const bool inside = (!zx || sx < hin) && (!zy || sy < hin) && (!zz || sz < hin);
+    unsure = !miss && !inside;
 }
 
 // (kx,ky,kz,h) = cube centre and half size, wave-uniform.  lo ~ tmin and hi ~ tmax of cube.rs:142-143,
@@ -560,6 +589,7 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
     const RayPre q = ray_pre(P, o, d);
     st.tol = q.tol;
     const CullPre cp = cull_pre(P, active, o, d, q.wild);
+    const bool any_zero = wave_any(active && q.zbits != 0u);
     PROF_MARK(PH_PRE);
     const uint32_t lane = threadIdx.x & 63u;
     const f32x4* filt = (const f32x4*)P.cube_filt;
@@ -588,6 +618,12 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
             bool sure = gap < -q.tol;  // proven to pass
             if constexpr (MODE == Q_NEAREST) sure = sure && (__builtin_fabsf(lo) > q.err);  // and the sign of tmin is certain
             if constexpr (MODE == Q_NEAREST_EXACT) sure = false;
+            if (any_zero) {
+                bool zmiss, zunsure;
+                zero_axis_check(q, o, kx, ky, kz, kh, zmiss, zunsure);
+                live = live && !zmiss;
+                sure = sure && !zunsure;
+            }
             const bool amb = live && !sure;
             float dist = (lo < 0.0f) ? hi : lo;  // cube.rs:145 on the approximate interval
             if (wave_any(amb)) {
