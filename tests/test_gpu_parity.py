@@ -175,3 +175,43 @@ def test_empty_scene_and_ragged_sizes(gpu_ctx, oracle_mod, default_scene):
     for w, h in [(37, 19), (129, 1), (1, 5), (17, 33)]:
         f, gfb, gpl, ofb, opl, _ = _both(gpu_ctx, oracle_mod, s, w, h)
         assert_parity(gfb, gpl, ofb, opl, f"ragged {w}x{h}")
+
+
+def _cam(eye, center, up=(0.0, 1.0, 0.0)):
+    return rt.Camera(rt.Vec3(*eye), rt.Vec3(*center), rt.Vec3(*up))
+
+
+@pytest.mark.parametrize("name,eye,center", [
+    ("looking away (cubes behind the eye are hit at negative t)", (0.0, 0.0, 10.0), (0.0, 0.0, 20.0)),
+    ("eye inside the diorama", (0.2, 1.0, 0.3), (3.0, 0.0, -3.0)),
+    ("far away", (0.0, 5.0, 200.0), (0.0, 0.0, 0.0)),
+    ("from above, nearly straight down", (0.0, 30.0, 0.01), (0.0, 0.0, 0.0)),
+    ("axis-aligned view, eye on a cube face plane", (0.75, 3.0, 12.0), (0.75, 3.0, 0.0)),
+    ("grazing the platform top", (-9.0, -0.75, 0.0), (9.0, -0.75, 0.0)),
+])
+def test_cameras_around_the_scene(gpu_ctx, oracle_mod, default_scene, name, eye, center):
+    """Camera placements that exercise the tile classification's give-up paths (corners beside/behind the
+    eye), negative-distance hits and rays with exactly-zero direction components (even frame width)."""
+    f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, default_scene, 256, 160, camera=_cam(eye, center))
+    assert_parity(gfb, gpl, ofb, opl, name)
+    c = gpu_ctx.count_rays(f)
+    assert c.uniq_dict() == ocnt.uniq_dict()
+
+
+def test_degenerate_cubes(gpu_ctx, oracle_mod, default_scene):
+    """Negative-size, zero-size, duplicated and eye-containing cubes, plus axis-parallel rays."""
+    s = default_scene
+    m = list(s.materials)
+    V = rt.Vec3
+    cubes = [rt.Cube(0, V(0.0, 0.0, 0.0), 2.0, 0),
+             rt.Cube(1, V(0.0, 0.0, 0.0), 2.0, 1 % len(m)),            # exact duplicate: lowest index must win
+             rt.Cube(2, V(3.0, 0.0, 0.0), -2.0, 2 % len(m)),           # min > max
+             rt.Cube(3, V(-3.0, 0.0, 0.0), 0.0, 3 % len(m)),           # a point
+             rt.Cube(4, V(0.0, 3.0, 1.0), 1.0, 4 % len(m)),
+             rt.Cube(5, V(0.0, 0.0, 9.0), 4.0, 5 % len(m)),            # contains the eye
+             rt.Cube(6, V(1.0, 0.0, 0.0), 2.0, 6 % len(m))]            # shares the face x = 1 ... 2 with cube 0/2
+    sc = rt.make_scene(cubes, [], m, list(s.lights), _cam((0.0, 0.0, 10.0), (0.0, 0.0, 0.0)), s.ambient_light, s.sky_0rgb, s.atlas)
+    for w, h in [(128, 96), (97, 64)]:
+        f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, w, h)
+        assert_parity(gfb, gpl, ofb, opl, f"degenerate cubes {w}x{h}")
+        assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
