@@ -46,6 +46,12 @@ struct rt_ctx {
     uint32_t* d_stamps = nullptr;
     size_t stamps_cap = 0;  // in words
     uint32_t frame_id = 0;
+    // work queue of the render kernel (build_queue)
+    uint32_t* d_queue = nullptr;
+    size_t queue_cap = 0;  // in words
+    // cycles per tile in the previous launch (orders the queue)
+    uint32_t* d_cost = nullptr;
+    size_t cost_cap = 0;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded pairs since last query
@@ -55,8 +61,8 @@ struct rt_ctx {
 namespace {
 
 #ifdef RTX_PROFILE
-constexpr size_t kProfWaves = 4u << 20;  // per-wave phase slots of the diagnostic build
-constexpr size_t kCounterBytes = 256 + kProfWaves * 16 * sizeof(uint32_t);
+constexpr size_t kProfWaves = 1u << 18;  // per-wave phase slots of the diagnostic build
+constexpr size_t kCounterBytes = 256 + kProfWaves * 40 * sizeof(uint32_t);
 #else
 constexpr size_t kCounterBytes = 32 * sizeof(unsigned long long);
 #endif
@@ -188,28 +194,58 @@ int ensure(rt_ctx* ctx, uint32_t** buf, size_t* cap, size_t need)
     return RT_OK;
 }
 
-// Stamps the tiles that some cube's projection touches (classify_tiles) and points `p` at them.  On
-// anything irregular (non-finite camera, skewed basis, non-finite bounds) p.tile_stamps stays null and
-// every tile is traced.
-int classify(rt_ctx* ctx, Params& p)
+// Per-launch preparation on the context's stream: the work queue (sized for the launch's tile grid, its
+// header zeroed) and the tile stamps (classify_tiles).  On anything irregular (non-finite camera, skewed
+// basis, non-finite bounds) p.tile_stamps stays null and every tile is traced.
+int prepare(rt_ctx* ctx, Params& p)
 {
     p.tile_stamps = nullptr;
     p.tiles_x = (p.width + 7u) / 8u;
     p.tiles_y = (p.height + 7u) / 8u;
     p.frame_id = 0u;
+    // tile grid of this launch: the part's 16-row blocks, two tile rows each
+    const uint32_t rows = p.y1 - p.y0;
+    const uint32_t blocks = (rows + kRowBlock - 1u) / kRowBlock;
+    const uint32_t my_blocks = (p.part < blocks) ? (blocks - p.part + p.n_parts - 1u) / p.n_parts : 0u;
+    p.grid_tx = p.tiles_x;
+    p.grid_ty = my_blocks * 2u;
+    const size_t n_tiles = (size_t)p.grid_tx * p.grid_ty;
+    const size_t qwords = kQueueBase + kCostClasses * n_tiles;
+    if (ctx->queue_cap < qwords) {
+        if (ctx->d_queue) HIP_TRY(ctx, hipFree(ctx->d_queue));
+        ctx->d_queue = nullptr;
+        ctx->queue_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_queue, qwords * sizeof(uint32_t)));
+        ctx->queue_cap = qwords;
+    }
+    p.queue = ctx->d_queue;
+    if (ctx->cost_cap < n_tiles + 1) {
+        if (ctx->d_cost) HIP_TRY(ctx, hipFree(ctx->d_cost));
+        ctx->d_cost = nullptr;
+        ctx->cost_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cost, (n_tiles + 1) * sizeof(uint32_t)));
+        ctx->cost_cap = n_tiles + 1;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_cost, 0, (n_tiles + 1) * sizeof(uint32_t), ctx->stream));  // 0 = unknown
+    }
+    p.tile_cost = ctx->d_cost;
+
     TileParams t;
     std::memset(&t, 0, sizeof(t));
+    bool regular = std::isfinite(p.bound_max);
     double mag = 1.0;
     for (int k = 0; k < 3; ++k) {
         t.eye[k] = p.eye[k]; t.right[k] = p.right[k]; t.up[k] = p.up[k]; t.fwd[k] = p.fwd[k];
-        if (!std::isfinite(t.eye[k]) || !std::isfinite(t.right[k]) || !std::isfinite(t.up[k]) || !std::isfinite(t.fwd[k])) return RT_OK;
+        if (!std::isfinite(t.eye[k]) || !std::isfinite(t.right[k]) || !std::isfinite(t.up[k]) || !std::isfinite(t.fwd[k])) regular = false;
         mag = std::max(mag, std::fabs(t.eye[k]));
     }
-    if (!std::isfinite(p.bound_max)) return RT_OK;
     mag = std::max(mag, (double)p.bound_max);
     const double* r = t.right; const double* u = t.up; const double* f = t.fwd;
     const double det = r[0] * (u[1] * f[2] - u[2] * f[1]) - r[1] * (u[0] * f[2] - u[2] * f[0]) + r[2] * (u[0] * f[1] - u[1] * f[0]);
-    if (!(std::fabs(det) > 0.5 && std::fabs(det) < 2.0)) return RT_OK;  // an orthonormal basis has |det| = 1
+    if (!(std::fabs(det) > 0.5 && std::fabs(det) < 2.0)) regular = false;  // an orthonormal basis has |det| = 1
+    if (!regular) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 16 * sizeof(uint32_t), ctx->stream));
+        return RT_OK;
+    }
     const size_t words = kStampBase + (size_t)p.tiles_x * p.tiles_y;
     if (ctx->stamps_cap < words) {
         if (ctx->d_stamps) HIP_TRY(ctx, hipFree(ctx->d_stamps));
@@ -232,10 +268,9 @@ int classify(rt_ctx* ctx, Params& p)
     t.width = p.width; t.height = p.height; t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y;
     t.stamps = ctx->d_stamps;
     t.frame_id = ctx->frame_id;
-    if (p.n_cubes > 0u) {
-        hipError_t e = (hipError_t)launch_classify(t, (void*)ctx->stream);
-        if (e != hipSuccess) return fail_hip(ctx, e, "classify kernel launch");
-    }
+    t.queue = ctx->d_queue;
+    hipError_t e = (hipError_t)launch_classify(t, (void*)ctx->stream);  // also zeroes the queue header
+    if (e != hipSuccess) return fail_hip(ctx, e, "classify kernel launch");
     p.tile_stamps = ctx->d_stamps;
     p.frame_id = ctx->frame_id;
     return RT_OK;
@@ -243,6 +278,8 @@ int classify(rt_ctx* ctx, Params& p)
 
 int launch_timed(rt_ctx* ctx, const Params& p, int variant)
 {
+    hipError_t e = (hipError_t)launch_queue(p, variant, (void*)ctx->stream);
+    if (e != hipSuccess) return fail_hip(ctx, e, "queue kernel launch");
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (ctx->timing) {
         if (!ctx->event_pool.empty()) {
@@ -254,7 +291,7 @@ int launch_timed(rt_ctx* ctx, const Params& p, int variant)
         }
         HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
     }
-    hipError_t e = (hipError_t)launch_render(p, variant, (void*)ctx->stream);
+    e = (hipError_t)launch_render(p, variant, (void*)ctx->stream);
     if (e != hipSuccess) return fail_hip(ctx, e, "render kernel launch");
     if (ctx->timing) {
         HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
@@ -305,6 +342,8 @@ int rt_ctx_destroy(rt_ctx* ctx)
     for (auto& b : ctx->d_dbg) (void)hipFree(b);
     (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_stamps);
+    (void)hipFree(ctx->d_queue);
+    (void)hipFree(ctx->d_cost);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(ctx->stream);
@@ -449,7 +488,7 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
 #ifdef RTX_PROFILE
     p.counters = ctx->d_counters;
 #endif
-    if ((rc = classify(ctx, p)) != RT_OK) return rc;
+    if ((rc = prepare(ctx, p)) != RT_OK) return rc;
     int variant = kVariantRender;
     if (dbg_device && (dbg_device->hit_cube || dbg_device->hit_sphere || dbg_device->tree_hash)) {
         p.hit_cube = dbg_device->hit_cube;
@@ -514,9 +553,10 @@ int rt_count_rays_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     p.n_parts = n_parts;
     p.part = part;
     p.counters = ctx->d_counters;
-    if ((rc = classify(ctx, p)) != RT_OK) return rc;
+    if ((rc = prepare(ctx, p)) != RT_OK) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
-    hipError_t e = (hipError_t)launch_render(p, kVariantCount, (void*)ctx->stream);
+    hipError_t e = (hipError_t)launch_queue(p, kVariantCount, (void*)ctx->stream);
+    if (e == hipSuccess) e = (hipError_t)launch_render(p, kVariantCount, (void*)ctx->stream);
     if (e != hipSuccess) return fail_hip(ctx, e, "count kernel launch");
     unsigned long long h[10];
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -554,30 +594,30 @@ int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches)
     }
 #ifdef RTX_PROFILE
     {
-        std::vector<uint32_t> h(kProfWaves * 16);
+        std::vector<uint32_t> h(kProfWaves * 40);
         HIP_TRY(ctx, hipMemcpy(h.data(), (char*)ctx->d_counters + 256, h.size() * 4, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemset((char*)ctx->d_counters + 256, 0, h.size() * 4));
         const char* names[10] = {"raygen", "pre(ray_pre+cull_pre)", "cull(+chunk load wait)", "candidates", "contested", "resolve", "shade", "shadow_post", "childsetup", "other"};
         double sum[10] = {0}; double tot = 0; size_t waves = 0; double mx = 0;
         for (size_t w = 0; w < kProfWaves; ++w) {
             double t = 0;
-            for (int k = 0; k < 10; ++k) { sum[k] += h[w * 16 + k]; t += h[w * 16 + k]; }
+            for (int k = 0; k < 10; ++k) { sum[k] += h[w * 40 + k]; t += h[w * 40 + k]; }
             if (t > 0) { ++waves; tot += t; if (t > mx) mx = t; }
         }
         fprintf(stderr, "[rtx950 profile, last launch] waves=%zu avg wave-cycles=%.0f max=%.0f\n", waves, tot / (waves ? waves : 1), mx);
         {   // slowest waves: tile position and phase split
             std::vector<std::pair<double, size_t>> top;
-            for (size_t w = 0; w < kProfWaves; ++w) { double t = 0; for (int k = 0; k < 10; ++k) t += h[w * 16 + k]; if (t > 0) top.push_back({t, w}); }
+            for (size_t w = 0; w < kProfWaves; ++w) { double t = 0; for (int k = 0; k < 10; ++k) t += h[w * 40 + k]; if (t > 0) top.push_back({t, w}); }
             std::sort(top.begin(), top.end()); std::reverse(top.begin(), top.end());
-            const size_t gx = 480;  // 3840/8 (diagnostic assumes the 4K bench frame)
+            const size_t gx = 480;  // 3840/8: tile grid of the 4K bench frame (diagnostic only)
             for (size_t i = 0; i < top.size() && i < 12; ++i) {
                 size_t w = top[i].second;
                 fprintf(stderr, "  slow wave %zu: tile x=%zu y=%zu cyc=%.0f :", i, (w % gx) * 8, (w / gx) * 8, top[i].first);
-                for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", h[w * 16 + k]);
+                for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", h[w * 40 + k]);
                 fprintf(stderr, "\n");
             }
             if (const char* dump = getenv("RTX950_PROF_DUMP")) {
-                if (FILE* f = fopen(dump, "wb")) { fwrite(h.data(), 4, (size_t)129600 * 16, f); fclose(f); }
+                if (FILE* f = fopen(dump, "wb")) { fwrite(h.data(), 4, (size_t)129600 * 40, f); fclose(f); }
             }
             size_t hist[8] = {0}; for (auto& t : top) { int b = 0; double v = t.first; while (v > 8192 && b < 7) { v /= 2; ++b; } hist[b]++; }
             fprintf(stderr, "  histogram of wave cycles (<=8K,16K,32K,64K,128K,256K,512K,more):"); for (int b = 0; b < 8; ++b) fprintf(stderr, " %zu", hist[b]); fprintf(stderr, "\n");

@@ -78,6 +78,14 @@ struct Params {
     const uint32_t* tile_stamps;
     uint32_t tiles_x, tiles_y;
     uint32_t frame_id;
+    // Work queue of this launch (build_queue -> render_kernel): words 0..7 = number of listed tiles per
+    // cost class (zeroed per frame by classify_tiles), class c's entries start at word kQueueBase + c *
+    // grid_tx * grid_ty; an entry is tile column | tile row << 16 in the launch's own grid of grid_tx x
+    // grid_ty 8x8 tiles.  tile_cost[row * grid_tx + column] = cycles the tile took in the previous launch
+    // on this context (0: unknown); it only orders the queue, heaviest class first.
+    uint32_t* queue;
+    uint32_t* tile_cost;
+    uint32_t grid_tx, grid_ty;
     float ambient;
     uint32_t sky;
     uint32_t max_depth;
@@ -104,13 +112,19 @@ struct TileParams {
     uint32_t width, height, tiles_x, tiles_y;
     uint32_t* stamps;
     uint32_t frame_id;
+    uint32_t* queue;  // header words 0..15 are zeroed by block 0
 };
 constexpr uint32_t kStampBase = 64;  // first per-tile word
+constexpr uint32_t kQueueBase = 64;  // first tile entry of Params::queue
+constexpr uint32_t kCostClasses = 8;
 
 enum KernelVariant { kVariantRender = 0, kVariantDebug = 1, kVariantCount = 2 };
 
 // Launches the render kernel for rows [y0,y1) on `stream` (hipStream_t passed as void*).
 // Returns a hipError_t as int.
+// launch_queue: lists the tiles that need tracing and paints the others (build_queue); launch_render:
+// one single-wave workgroup per possible tile.  Both return a hipError_t.
+int launch_queue(const Params& p, int variant, void* stream);
 int launch_render(const Params& p, int variant, void* stream);
 int launch_classify(const TileParams& t, void* stream);
 

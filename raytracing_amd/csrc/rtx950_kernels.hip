@@ -456,13 +456,19 @@ DEV float powf_like_libm(float x, float y)
 // -DRTX_PROFILE adds s_memtime stamps around the phases of a traversal; the per-wave sums go to
 // P.counters[16..] (memory no output depends on).  Never enabled in the shipped library.
 #ifdef RTX_PROFILE
-struct Prof { uint32_t t[10]; uint32_t last; };
+struct Prof { uint32_t t[10]; uint32_t last; uint32_t c[8]; uint32_t kind; uint32_t qk[8]; uint32_t ck[8]; };
 __device__ Prof* g_prof_unused;
-#define PROF_DECL Prof prof; for (int k_ = 0; k_ < 10; ++k_) prof.t[k_] = 0u; prof.last = (uint32_t)__builtin_readcyclecounter(); const uint32_t prof_t0 = prof.last; const uint32_t prof_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#define PROF_DECL Prof prof; for (int k_ = 0; k_ < 10; ++k_) prof.t[k_] = 0u; for (int k_ = 0; k_ < 8; ++k_) { prof.c[k_] = 0u; prof.qk[k_] = 0u; prof.ck[k_] = 0u; } prof.kind = 0u; prof.last = (uint32_t)__builtin_readcyclecounter(); const uint32_t prof_t0 = prof.last; const uint32_t prof_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #define PROF_ARG , Prof& prof
 #define PROF_PASS , prof
 #define PROF_MARK(k) do { uint32_t n_ = (uint32_t)__builtin_readcyclecounter(); prof.t[k] += n_ - prof.last; prof.last = n_; } while (0)
+#define PROF_COUNT(k, n) do { prof.c[k] += (uint32_t)(n); } while (0)
+#define PROF_KIND(k) do { prof.kind = (k); } while (0)
+#define PROF_KCOUNT(arr, n) do { prof.arr[prof.kind & 7u] += (uint32_t)(n); } while (0)
 #else
+#define PROF_KIND(k) do { } while (0)
+#define PROF_KCOUNT(arr, n) do { } while (0)
+#define PROF_COUNT(k, n) do { } while (0)
 #define PROF_DECL
 #define PROF_ARG
 #define PROF_PASS
@@ -515,6 +521,7 @@ struct CullPre {  // wave-uniform
     float wxyc, wyzc, wzxc;     // its moment
     float dr;                   // max over active lanes and axes of |d - dc|
     float wr;                   // same for the moment, plus rounding slack
+    float wr_raw;               // ... without the slack
     float sxy, syz, szx;        // upper bounds of |d_i| + |d_j|
     bool all;                   // some active ray is non-finite or huge: keep every cube
 };
@@ -544,6 +551,7 @@ DEV CullPre cull_pre(const Params& P, bool active, V3 o, V3 d, bool wild)
     // 2^-17 (B + O + 1) max(D, 1) = 128 u (...) covers both several times over.
     const float slack = 0x1p-17f * (P.bound_max + omax + 1.0f) * __builtin_fmaxf(ax + ay + az, 1.0f);
     c.wr = wrm + slack;
+    c.wr_raw = wrm;
     return c;
 }
 
@@ -582,14 +590,13 @@ struct QState {
 //   Q_NEAREST_EXACT  exact evaluation of every candidate for the lanes in `active`.
 //   Q_SHADOW         render.rs:44-70 list-order semantics, exclusion by id (render.rs:113).
 template <int MODE>
-DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
+DEV void cube_query_group(const Params& P, const RayPre& q, const CullPre& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
     const uint32_t n = P.n_cubes;
-    if (n == 0u) return;
-    const RayPre q = ray_pre(P, o, d);
-    st.tol = q.tol;
-    const CullPre cp = cull_pre(P, active, o, d, q.wild);
     const bool any_zero = wave_any(active && q.zbits != 0u);
+    PROF_COUNT(6, 1);
+    PROF_KCOUNT(qk, 1);
+    PROF_COUNT(7, __builtin_popcountll(wave_ballot(active)));
     PROF_MARK(PH_PRE);
     const uint32_t lane = threadIdx.x & 63u;
     const f32x4* filt = (const f32x4*)P.cube_filt;
@@ -626,6 +633,13 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
             }
             const bool amb = live && !sure;
             float dist = (lo < 0.0f) ? hi : lo;  // cube.rs:145 on the approximate interval
+            PROF_COUNT(0, 1);
+            PROF_KCOUNT(ck, 1);
+            PROF_COUNT(1, wave_any(amb) ? 1 : 0);
+            PROF_COUNT(2, __builtin_popcountll(wave_ballot(amb && q.unsafe)));
+            PROF_COUNT(3, __builtin_popcountll(wave_ballot(amb && !q.unsafe && !(gap < -q.tol))));
+            PROF_COUNT(4, __builtin_popcountll(wave_ballot(amb && !q.unsafe && (gap < -q.tol))));
+            PROF_COUNT(5, __builtin_popcountll(wave_ballot(live)));
             if (wave_any(amb)) {
                 if (amb) {
                     const CubeRec c = load_cube_uniform(P.cubes, i);
@@ -660,6 +674,19 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
         PROF_MARK(PH_CAND);
         rec = nxt;
     }
+}
+
+// (An attempt to split a wave whose lanes carry two ray bundles - an 8x8 tile across a cube edge makes
+// every cube a candidate of the wave-level cull - into per-bundle passes cut the candidate count by a
+// fifth and was still 8 % slower overall: the extra cull set-ups and the register pressure cost more.)
+template <int MODE>
+DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
+{
+    if (P.n_cubes == 0u) return;
+    const RayPre q = ray_pre(P, o, d);
+    st.tol = q.tol;
+    const CullPre cp = cull_pre(P, active, o, d, q.wild);
+    cube_query_group<MODE>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
 }
 
 // ---------------------------------------------------------------- nearest hit (render.rs:87-101)
@@ -815,6 +842,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
             // ------------------------------------------------ one node: nearest hit, shading, child rays
             Counters cnt = {0u, 0u, 0u, 0u, 0u};
             PROF_MARK(PH_OTHER);
+            PROF_KIND(depth * 2u);
             const uint32_t idx = nearest_query<COUNT>(P, pass, act, o, d, cnt PROF_PASS);
             if (depth == 0u) hit_idx = idx;
             uint32_t h = hmix(kHashBasis, idx);
@@ -847,6 +875,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     const V3 reflect_dir = vnormalize(reflect(vneg(light_dir), hit.n));
                     uint32_t blocker;
                     PROF_MARK(PH_SHADE);
+                    PROF_KIND(depth * 2u + 1u);
                     const float shadow = shadow_query<COUNT>(P, pass, hit_any, hit.p, lp, hit.id, blocker, cnt PROF_PASS);
                     if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
                     const float light_intensity = L.intensity * (1.0f - shadow);
@@ -956,9 +985,97 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
 }
 
 // ---------------------------------------------------------------- render (render.rs:234-324)
-// One lane per pixel; a wave (= one workgroup) covers an 8x8 pixel tile: coherent rays give tight
-// wave-level bounds in the cull, and single-wave workgroups retire independently (a 16x16 tile of 4
-// waves holds its 4 slots until the slowest wave is done: measured 20 % of the slots idle).
+// Geometry of a launch: the band [y0,y1) is cut into 16-row blocks, part p of n_parts owns blocks p,
+// p+n_parts, ... and stores them compactly; each block is two rows of 8x8 pixel tiles.  Tile (bx, by) of
+// the launch's grid covers frame rows tile_y0(by) .. +7 and output rows by*8 .. +7.
+DEV uint32_t tile_y0(const Params& P, uint32_t by) { return P.y0 + ((by >> 1) * P.n_parts + P.part) * kRowBlock + (by & 1u) * 8u; }
+
+// No cube's projection touches the tile (classify_tiles)?  The render tile is aligned to the band
+// start y0, so it can straddle two rows of the frame-aligned classification tiles.  Wave-uniform.
+DEV bool tile_has_no_cubes(const Params& P, uint32_t bx, uint32_t ty0)
+{
+    if (!P.tile_stamps) return false;
+    const uint32_t last = P.tiles_y - 1u;
+    const uint32_t r0 = (ty0 >> 3) < last ? (ty0 >> 3) : last;
+    const uint32_t r1 = ((ty0 + 7u) >> 3) < last ? ((ty0 + 7u) >> 3) : last;
+    const uint32_t* st = P.tile_stamps;
+    const uint32_t s_all = st[0], s0 = st[kStampBase + r0 * P.tiles_x + bx], s1 = st[kStampBase + r1 * P.tiles_x + bx];
+    return (s_all != P.frame_id) && (s0 != P.frame_id) && (s1 != P.frame_id);
+}
+
+// build_queue: one thread per tile of the launch.  A tile whose primary rays can hit nothing (no
+// spheres in the scene and no cube projecting into it) is painted here: sky colour, "no hit" planes,
+// and the rays the reference would still have cast are counted.  Every other tile is appended to the
+// work queue of the persistent render kernel.  (A wave per such tile cost 2-3 us of slot time for
+// nothing: 77 % of the 4K benchmark frame's tiles.)
+template <bool DBG, bool COUNT>
+__global__ __launch_bounds__(256) void build_queue(const Params P)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool valid = t < P.grid_tx * P.grid_ty;
+    const uint32_t bx = valid ? t % P.grid_tx : 0u, by = valid ? t / P.grid_tx : 0u;
+    const uint32_t ty0 = tile_y0(P, by);
+    const bool in_band = valid && (ty0 < P.y1);
+    const bool listed = in_band && ((P.n_spheres != 0u) || !tile_has_no_cubes(P, bx, ty0));
+    // cost class from the tile's cycle count in the previous launch: < 8K cycles -> 0, then one class per
+    // doubling, >= 512K -> 7
+    const uint32_t cost = valid ? P.tile_cost[t] : 0u;
+    const uint32_t bits = 32u - (uint32_t)__builtin_clz(cost | 1u);
+    const uint32_t cls = bits <= 13u ? 0u : (bits - 13u > kCostClasses - 1u ? kCostClasses - 1u : bits - 13u);
+    // wave-aggregated append to the class's list
+    const uint32_t tiles = P.grid_tx * P.grid_ty;
+    for (uint32_t k = 0; k < kCostClasses; ++k) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(listed && cls == k);
+        if (m == 0ull) continue;
+        const uint32_t first = (uint32_t)__builtin_ctzll(m);
+        uint32_t base = 0u;
+        if (lane == first) base = atomicAdd(&P.queue[k], (uint32_t)__builtin_popcountll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+        if (listed && cls == k) P.queue[kQueueBase + k * tiles + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = bx | (by << 16);
+    }
+    unsigned long long n_px = 0ull;
+    if (in_band && !listed) {
+        const uint32_t x0 = bx * 8u;
+        const uint32_t nx = (P.width - x0) < 8u ? (P.width - x0) : 8u;
+        const uint32_t no_hash = hmix(kHashBasis, kNoHit);
+        const uint32_t px_hash = hmix(hmix(kHashBasis, no_hash), no_hash);
+        for (uint32_t r = 0; r < 8u; ++r) {
+            const uint32_t y = ty0 + r;
+            if (y >= P.y1) break;
+            const size_t i_band = (size_t)(by * 8u + r) * P.width + x0;
+            for (uint32_t i = 0; i < nx; ++i) {
+                if constexpr (!COUNT) {
+                    // render.rs:316-322: pixel i == width is never painted
+                    if (P.out) P.out[i_band + i] = ((size_t)y * P.width + x0 + i == (size_t)P.width) ? 0u : P.sky;
+                }
+                if constexpr (DBG) {
+                    if (P.hit_cube) P.hit_cube[i_band + i] = kNoHit;
+                    if (P.hit_sphere) P.hit_sphere[i_band + i] = kNoHit;
+                    if (P.tree_hash) P.tree_hash[i_band + i] = px_hash;
+                }
+            }
+            n_px += nx;
+        }
+    }
+    if constexpr (COUNT) {
+        // per pixel: one nearest-hit walk of the (empty) sphere list and one of the cube list
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n_px += __shfl_down(n_px, off, 64);
+        if (lane == 0u && n_px != 0ull) {
+            atomicAdd(&P.counters[0], 2ull * n_px); atomicAdd(&P.counters[5], 2ull * n_px);
+            atomicAdd(&P.counters[2], n_px * P.n_cubes); atomicAdd(&P.counters[7], n_px * P.n_cubes);
+        }
+    }
+}
+
+// render_kernel: single-wave workgroups, one lane per pixel of an 8x8 tile (coherent rays give tight
+// wave-level bounds in the cull; a wave retires on its own instead of holding a 4-wave workgroup's
+// slots).  One workgroup per POSSIBLE tile; workgroup i takes the i-th entry of the queue in
+// heaviest-class-first order and leaves at once if there is none.  The hardware dispatcher is the
+// dynamic scheduler: the frame time is bounded below by "start of the slowest tile + its duration", so
+// the slow tiles (as measured in the previous launch) go first.  (A persistent variant taking tickets
+// with atomicAdd lost 75 us per 4K frame to same-address atomic traffic.)
 #ifndef RTX_WAVES_PER_EU
 #define RTX_WAVES_PER_EU 4
 #endif
@@ -967,105 +1084,102 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
 {
     __shared__ uint32_t stk[kStackDepth * frame_words<DBG>() * 64];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t x = blockIdx.x * 8u + (lane & 7u);
-    const uint32_t ly = (blockIdx.y & 1u) * 8u + (lane >> 3);
-    // interleaved parts: this launch renders 16-row blocks part, part+n_parts, ... of [y0,y1)
-    const uint32_t blk = blockIdx.y >> 1;
-    const uint32_t y = P.y0 + (blk * P.n_parts + P.part) * kRowBlock + ly;
-    const uint32_t out_row = blk * kRowBlock + ly;
     Totals cnt;
 #pragma unroll
     for (int k = 0; k < 10; ++k) cnt.v[k] = 0ull;
-    PROF_DECL
-    const bool active = (x < P.width) && (y < P.y1);  // lanes outside the frame stay in the wave, inactive
-
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    // the queue is final: build_queue has completed
+    uint32_t idx = blockIdx.x, entry = 0xFFFFFFFFu;
+    {
+        const uint32_t tiles = P.grid_tx * P.grid_ty;
+        KCONST uint32_t* q = (KCONST uint32_t*)P.queue;
+        bool found = false;
+        for (uint32_t k = kCostClasses; k-- > 0u;) {
+            const uint32_t n_k = q[k];
+            if (!found && idx < n_k) {
+                entry = q[kQueueBase + k * tiles + idx];
+                found = true;
+            }
+            idx -= found ? 0u : n_k;
+        }
+        if (!found) return;
+    }
     const float width = (float)P.width, height = (float)P.height;
     const float aspect = width / height;
-    float sx = (2.0f * (float)x) / width - 1.0f;
-    const float sy = -(2.0f * (float)y) / height + 1.0f;
-    sx = sx * aspect;
-    const V3 v = vnormalize(v3(sx, sy, -1.0f));
-    // camera.rs:38-40: v.x*right + v.y*up - v.z*forward, normalised
     const V3 right = v3(P.right[0], P.right[1], P.right[2]);
     const V3 up = v3(P.up[0], P.up[1], P.up[2]);
     const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
-    const V3 dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));
     const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
+    {
+        const uint32_t bx = entry & 0xFFFFu, by = entry >> 16;
+        const uint32_t ty0 = tile_y0(P, by);
+        const uint32_t x = bx * 8u + (lane & 7u);
+        const uint32_t y = ty0 + (lane >> 3);
+        const uint32_t out_row = by * 8u + (lane >> 3);
+        PROF_DECL
+        const bool active = (x < P.width) && (y < P.y1);  // lanes outside the frame stay in the wave, inactive
 
-    PROF_MARK(PH_RAYGEN);
-#if defined(RTX_EXP) && RTX_EXP == 1
-    if constexpr (!DBG && !COUNT) {
-        if (active && P.out) P.out[(size_t)out_row * P.width + x] = __builtin_bit_cast(uint32_t, dir.x + dir.y + dir.z + eye.x);
-        return;
-    }
-#elif defined(RTX_EXP) && RTX_EXP == 0
-    if constexpr (!DBG && !COUNT) {
-        if (active && P.out) P.out[(size_t)out_row * P.width + x] = x + y;
-        return;
-    }
-#endif
-    // render.rs:298-312: a spheres-only pass with ambient 1, a cubes-only pass with ambient_light; the
-    // sphere colour wins unless it equals the sky colour
-    uint32_t px = 0u, hs = 0u, hc = 0u, hit_s = kNoHit, hit_c = kNoHit;
-    // Passes that cannot hit anything are not traced (wave-uniform): no spheres at all, or an 8x8 tile
-    // that no cube's projection touches (classify_tiles).  The render tile is aligned to the band
-    // start y0, so it can straddle two rows of the frame-aligned classification tiles.
-    bool no_cubes = false;
-    if (P.tile_stamps) {
-        const uint32_t ty0 = P.y0 + (blk * P.n_parts + P.part) * kRowBlock + (blockIdx.y & 1u) * 8u;
-        const uint32_t last = P.tiles_y - 1u;
-        const uint32_t r0 = (ty0 >> 3) < last ? (ty0 >> 3) : last;
-        const uint32_t r1 = ((ty0 + 7u) >> 3) < last ? ((ty0 + 7u) >> 3) : last;
-        KCONST uint32_t* st = (KCONST uint32_t*)P.tile_stamps;
-        const uint32_t s_all = st[0], s0 = st[kStampBase + r0 * P.tiles_x + blockIdx.x], s1 = st[kStampBase + r1 * P.tiles_x + blockIdx.x];
-        no_cubes = (s_all != P.frame_id) && (s0 != P.frame_id) && (s1 != P.frame_id);
-    }
-    for (uint32_t pass = PASS_SPHERES; pass <= PASS_CUBES; ++pass) {
-        uint32_t hh, hi, c;
-        const bool skip = (pass == PASS_SPHERES) ? (P.n_spheres == 0u) : no_cubes;
-        if (skip) {
-            c = P.sky;
-            hi = kNoHit;
-            hh = hmix(kHashBasis, kNoHit);
-            if constexpr (COUNT) {  // the reference still walks the list for this ray
-                const unsigned long long one = active ? 1ull : 0ull, tests = (pass == PASS_CUBES && active) ? P.n_cubes : 0ull;
-                cnt.v[0] += one; cnt.v[5] += one;
-                cnt.v[2] += tests; cnt.v[7] += tests;
+        float sx = (2.0f * (float)x) / width - 1.0f;
+        const float sy = -(2.0f * (float)y) / height + 1.0f;
+        sx = sx * aspect;
+        const V3 v = vnormalize(v3(sx, sy, -1.0f));
+        // camera.rs:38-40: v.x*right + v.y*up - v.z*forward, normalised
+        const V3 dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));
+        PROF_MARK(PH_RAYGEN);
+
+        // render.rs:298-312: a spheres-only pass with ambient 1, a cubes-only pass with ambient_light; the
+        // sphere colour wins unless it equals the sky colour.  Passes that cannot hit anything are not
+        // traced (wave-uniform): no spheres at all, or no cube projecting into the tile.
+        uint32_t px = 0u, hs = 0u, hc = 0u, hit_s = kNoHit, hit_c = kNoHit;
+        const bool no_cubes = tile_has_no_cubes(P, bx, ty0);
+        for (uint32_t pass = PASS_SPHERES; pass <= PASS_CUBES; ++pass) {
+            uint32_t hh, hi, c;
+            const bool skip = (pass == PASS_SPHERES) ? (P.n_spheres == 0u) : no_cubes;
+            if (skip) {
+                c = P.sky;
+                hi = kNoHit;
+                hh = hmix(kHashBasis, kNoHit);
+                if constexpr (COUNT) {  // the reference still walks the list for this ray
+                    const unsigned long long one = active ? 1ull : 0ull, tests = (pass == PASS_CUBES && active) ? P.n_cubes : 0ull;
+                    cnt.v[0] += one; cnt.v[5] += one;
+                    cnt.v[2] += tests; cnt.v[7] += tests;
+                }
+            } else {
+                c = trace_tree<DBG, COUNT>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
             }
-        } else {
-            c = trace_tree<DBG, COUNT>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
+            if (pass == PASS_SPHERES) { px = c; hs = hh; hit_s = hi; }
+            else { px = (px == P.sky) ? c : px; hc = hh; hit_c = hi; }
         }
-        if (pass == PASS_SPHERES) { px = c; hs = hh; hit_s = hi; }
-        else { px = (px == P.sky) ? c : px; hc = hh; hit_c = hi; }
-    }
-    PROF_MARK(PH_OTHER);
-    const size_t i_frame = (size_t)y * P.width + x;
-    if (i_frame == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
-    const size_t i_band = (size_t)out_row * P.width + x;
-    if (active) {
-        if constexpr (!COUNT) {
-            if (P.out) P.out[i_band] = px;
+        PROF_MARK(PH_OTHER);
+        const size_t i_frame = (size_t)y * P.width + x;
+        if (i_frame == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
+        const size_t i_band = (size_t)out_row * P.width + x;
+        if (active) {
+            if constexpr (!COUNT) {
+                if (P.out) P.out[i_band] = px;
+            }
+            if constexpr (DBG) {
+                if (P.hit_cube) P.hit_cube[i_band] = hit_c;
+                if (P.hit_sphere) P.hit_sphere[i_band] = hit_s;
+                if (P.tree_hash) P.tree_hash[i_band] = hmix(hmix(kHashBasis, hs), hc);
+            }
         }
-        if constexpr (DBG) {
-            if (P.hit_cube) P.hit_cube[i_band] = hit_c;
-            if (P.hit_sphere) P.hit_sphere[i_band] = hit_s;
-            if (P.tree_hash) P.tree_hash[i_band] = hmix(hmix(kHashBasis, hs), hc);
-        }
-    }
+        if (lane == 0u) P.tile_cost[(size_t)by * P.grid_tx + bx] = (uint32_t)(__builtin_readcyclecounter() - t_start) | 1u;
 #ifdef RTX_PROFILE
-    PROF_MARK(PH_OTHER);
-    if (lane == 0u && P.counters) {
-        // per-wave slots (no atomics: contended atomics would dominate the run); the host reads them
-        uint32_t* slot = (uint32_t*)P.counters + 64 + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16u;
-        for (int k = 0; k < 10; ++k) slot[k] = prof.t[k];
-        slot[10] = prof_t0;
-        slot[11] = prof.last;
-        slot[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave/simd/cu/sh/se
-        slot[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
-        slot[14] = prof_r0;
-        slot[15] = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz, common to the chip
-    }
+        PROF_MARK(PH_OTHER);
+        if (lane == 0u && P.counters) {
+            // per-tile slots (no atomics: contended atomics would dominate the run); the host reads them
+            uint32_t* slot = (uint32_t*)P.counters + 64 + ((size_t)by * P.grid_tx + bx) * 40u;
+            for (int k = 0; k < 10; ++k) slot[k] = prof.t[k];
+            slot[10] = prof_t0;
+            slot[11] = prof.last;
+            slot[12] = prof_r0;
+            slot[13] = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz, common to the chip
+            slot[14] = blockIdx.x;
+            for (int k = 0; k < 8; ++k) { slot[16 + k] = prof.c[k]; slot[24 + k] = prof.qk[k]; slot[32 + k] = prof.ck[k]; }
+        }
 #endif
+    }
     if constexpr (COUNT) {
         // wave reduction, then one atomic per wave and counter
 #pragma unroll
@@ -1092,6 +1206,7 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
 {
     const uint32_t cube = blockIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
+    if (cube == 0u && lane < 16u) T.queue[lane] = 0u;  // the work queue header of this frame's launch
     if (cube >= T.n_cubes) return;
     const float* rec = T.cube_filt + (size_t)cube * 4u;
     const double h = __builtin_fabs((double)rec[3]) + T.pad;
@@ -1137,20 +1252,30 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
 
 int launch_classify(const TileParams& t, void* stream)
 {
-    if (t.n_cubes == 0u) return (int)hipSuccess;
-    hipLaunchKernelGGL(classify_tiles, dim3(t.n_cubes, 1u, 1u), dim3(64u, 1u, 1u), 0, (hipStream_t)stream, t);
+    // at least one block: block 0 also zeroes the work queue header
+    hipLaunchKernelGGL(classify_tiles, dim3(t.n_cubes ? t.n_cubes : 1u, 1u, 1u), dim3(64u, 1u, 1u), 0, (hipStream_t)stream, t);
+    return (int)hipGetLastError();
+}
+
+int launch_queue(const Params& p, int variant, void* stream)
+{
+    const uint32_t tiles = p.grid_tx * p.grid_ty;
+    if (tiles == 0u) return (int)hipSuccess;
+    dim3 grid((tiles + 255u) / 256u, 1u, 1u), block(256u, 1u, 1u);
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+    case kVariantDebug: hipLaunchKernelGGL((build_queue<true, false>), grid, block, 0, s, p); break;
+    case kVariantCount: hipLaunchKernelGGL((build_queue<false, true>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((build_queue<false, false>), grid, block, 0, s, p); break;
+    }
     return (int)hipGetLastError();
 }
 
 int launch_render(const Params& p, int variant, void* stream)
 {
-    const uint32_t rows = p.y1 - p.y0;
-    const uint32_t blocks = (rows + kRowBlock - 1u) / kRowBlock;
-    if (p.n_parts == 0u || p.part >= p.n_parts) return (int)hipErrorInvalidValue;
-    if (p.part >= blocks) return (int)hipSuccess;  // this part owns no rows
-    const uint32_t my_blocks = (blocks - p.part + p.n_parts - 1u) / p.n_parts;
-    dim3 grid((p.width + 7u) / 8u, my_blocks * 2u, 1u);  // one 8x8 tile per single-wave workgroup
-    dim3 block(64u, 1u, 1u);
+    const uint32_t tiles = p.grid_tx * p.grid_ty;
+    if (tiles == 0u) return (int)hipSuccess;
+    dim3 grid(tiles, 1u, 1u), block(64u, 1u, 1u);  // single-wave workgroups; those beyond the queue's length exit at once
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
     case kVariantDebug: hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, s, p); break;
