@@ -210,7 +210,7 @@ int prepare(rt_ctx* ctx, Params& p)
     p.grid_tx = p.tiles_x;
     p.grid_ty = my_blocks * 2u;
     const size_t n_tiles = (size_t)p.grid_tx * p.grid_ty;
-    const size_t qwords = kQueueBase + kCostClasses * n_tiles;
+    const size_t qwords = kQueueBase + (kCostClasses + 1) * n_tiles;
     if (ctx->queue_cap < qwords) {
         if (ctx->d_queue) HIP_TRY(ctx, hipFree(ctx->d_queue));
         ctx->d_queue = nullptr;

@@ -78,9 +78,9 @@ struct Params {
     const uint32_t* tile_stamps;
     uint32_t tiles_x, tiles_y;
     uint32_t frame_id;
-    // Work queue of this launch (build_queue -> render_kernel): words 0..7 = number of listed tiles per
-    // cost class (zeroed per frame by classify_tiles), class c's entries start at word kQueueBase + c *
-    // grid_tx * grid_ty; an entry is tile column | tile row << 16 in the launch's own grid of grid_tx x
+    // Work queue of this launch (build_queue -> render_kernel): words 0..8 = number of listed tiles per
+    // class (zeroed per frame by classify_tiles; classes 0..7 = traced tiles by cost, class 8 = tiles that
+    // are only painted), class c's entries start at word kQueueBase + c * grid_tx * grid_ty; an entry is tile column | tile row << 16 in the launch's own grid of grid_tx x
     // grid_ty 8x8 tiles.  tile_cost[row * grid_tx + column] = cycles the tile took in the previous launch
     // on this context (0: unknown); it only orders the queue, heaviest class first.
     uint32_t* queue;

@@ -802,6 +802,7 @@ DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V
 //    instruction cache - and several hundred spilled registers.)
 // Frame of a node waiting for its children, per lane:
 enum { F_RO = 0, F_RD = 3, F_SUMF = 6, F_C0 = 7, F_KR = 8, F_KT = 9, F_H = 10, F_H0 = 11 };
+constexpr uint32_t kPaintGroup = 16;  // untraced tiles painted per surplus workgroup
 constexpr int kStackDepth = 3;  // nodes at depth 0..2 can wait for traced children (max_depth <= 3)
 template <bool DBG>
 constexpr int frame_words() { return DBG ? 12 : 10; }
@@ -1003,70 +1004,35 @@ DEV bool tile_has_no_cubes(const Params& P, uint32_t bx, uint32_t ty0)
     return (s_all != P.frame_id) && (s0 != P.frame_id) && (s1 != P.frame_id);
 }
 
-// build_queue: one thread per tile of the launch.  A tile whose primary rays can hit nothing (no
-// spheres in the scene and no cube projecting into it) is painted here: sky colour, "no hit" planes,
-// and the rays the reference would still have cast are counted.  Every other tile is appended to the
-// work queue of the persistent render kernel.  (A wave per such tile cost 2-3 us of slot time for
-// nothing: 77 % of the 4K benchmark frame's tiles.)
-template <bool DBG, bool COUNT>
-__global__ __launch_bounds__(256) void build_queue(const Params P)
+// build_queue: one thread per tile of the launch appends the tile to one of the queue's lists.  A
+// tile whose primary rays can hit nothing (no spheres in the scene and no cube projecting into it) goes
+// to the last list (class kCostClasses): the render kernel paints it without tracing, after all traced
+// tiles have been handed out.  Every other tile goes to the list of its cost class.
+__global__ __launch_bounds__(1024) void build_queue(const Params P)
 {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    const bool valid = t < P.grid_tx * P.grid_ty;
+    const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t tiles = P.grid_tx * P.grid_ty;
+    const bool valid = t < tiles;
     const uint32_t bx = valid ? t % P.grid_tx : 0u, by = valid ? t / P.grid_tx : 0u;
     const uint32_t ty0 = tile_y0(P, by);
     const bool in_band = valid && (ty0 < P.y1);
-    const bool listed = in_band && ((P.n_spheres != 0u) || !tile_has_no_cubes(P, bx, ty0));
+    const bool traced = in_band && ((P.n_spheres != 0u) || !tile_has_no_cubes(P, bx, ty0));
     // cost class from the tile's cycle count in the previous launch: < 8K cycles -> 0, then one class per
     // doubling, >= 512K -> 7
     const uint32_t cost = valid ? P.tile_cost[t] : 0u;
     const uint32_t bits = 32u - (uint32_t)__builtin_clz(cost | 1u);
-    const uint32_t cls = bits <= 13u ? 0u : (bits - 13u > kCostClasses - 1u ? kCostClasses - 1u : bits - 13u);
-    // wave-aggregated append to the class's list
-    const uint32_t tiles = P.grid_tx * P.grid_ty;
-    for (uint32_t k = 0; k < kCostClasses; ++k) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(listed && cls == k);
-        if (m == 0ull) continue;
-        const uint32_t first = (uint32_t)__builtin_ctzll(m);
-        uint32_t base = 0u;
-        if (lane == first) base = atomicAdd(&P.queue[k], (uint32_t)__builtin_popcountll(m));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
-        if (listed && cls == k) P.queue[kQueueBase + k * tiles + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = bx | (by << 16);
-    }
-    unsigned long long n_px = 0ull;
-    if (in_band && !listed) {
-        const uint32_t x0 = bx * 8u;
-        const uint32_t nx = (P.width - x0) < 8u ? (P.width - x0) : 8u;
-        const uint32_t no_hash = hmix(kHashBasis, kNoHit);
-        const uint32_t px_hash = hmix(hmix(kHashBasis, no_hash), no_hash);
-        for (uint32_t r = 0; r < 8u; ++r) {
-            const uint32_t y = ty0 + r;
-            if (y >= P.y1) break;
-            const size_t i_band = (size_t)(by * 8u + r) * P.width + x0;
-            for (uint32_t i = 0; i < nx; ++i) {
-                if constexpr (!COUNT) {
-                    // render.rs:316-322: pixel i == width is never painted
-                    if (P.out) P.out[i_band + i] = ((size_t)y * P.width + x0 + i == (size_t)P.width) ? 0u : P.sky;
-                }
-                if constexpr (DBG) {
-                    if (P.hit_cube) P.hit_cube[i_band + i] = kNoHit;
-                    if (P.hit_sphere) P.hit_sphere[i_band + i] = kNoHit;
-                    if (P.tree_hash) P.tree_hash[i_band + i] = px_hash;
-                }
-            }
-            n_px += nx;
-        }
-    }
-    if constexpr (COUNT) {
-        // per pixel: one nearest-hit walk of the (empty) sphere list and one of the cube list
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) n_px += __shfl_down(n_px, off, 64);
-        if (lane == 0u && n_px != 0ull) {
-            atomicAdd(&P.counters[0], 2ull * n_px); atomicAdd(&P.counters[5], 2ull * n_px);
-            atomicAdd(&P.counters[2], n_px * P.n_cubes); atomicAdd(&P.counters[7], n_px * P.n_cubes);
-        }
-    }
+    const uint32_t cls = !traced ? kCostClasses : (bits <= 13u ? 0u : (bits - 13u > kCostClasses - 1u ? kCostClasses - 1u : bits - 13u));
+    // block-aggregated append to the class's list: one atomicAdd per block and class (same-address
+    // atomics are the slow part: ~3 ns each, device-wide)
+    __shared__ uint32_t n_cls[kCostClasses + 1], base_cls[kCostClasses + 1];
+    if (threadIdx.x <= kCostClasses) n_cls[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t rank = 0u;
+    if (in_band) rank = atomicAdd(&n_cls[cls], 1u);
+    __syncthreads();
+    if (threadIdx.x <= kCostClasses) base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[threadIdx.x], n_cls[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (in_band) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (by << 16);
 }
 
 // render_kernel: single-wave workgroups, one lane per pixel of an 8x8 tile (coherent rays give tight
@@ -1090,6 +1056,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
     const unsigned long long t_start = __builtin_readcyclecounter();
     // the queue is final: build_queue has completed
     uint32_t idx = blockIdx.x, entry = 0xFFFFFFFFu;
+    bool painted = false;
     {
         const uint32_t tiles = P.grid_tx * P.grid_ty;
         KCONST uint32_t* q = (KCONST uint32_t*)P.queue;
@@ -1102,15 +1069,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
             }
             idx -= found ? 0u : n_k;
         }
-        if (!found) return;
+        if (!found) {
+            // The traced tiles are all handed out: this workgroup paints kPaintGroup of the others (sky
+            // colour, "no hit" planes) and counts the rays the reference would still have cast for them.
+            KCONST uint32_t* sky_list = q + kQueueBase + kCostClasses * tiles;
+            const uint32_t n_sky = q[kCostClasses];
+            const uint32_t no_hash = hmix(kHashBasis, kNoHit);
+            const uint32_t px_hash = hmix(hmix(kHashBasis, no_hash), no_hash);
+            for (uint32_t j = idx * kPaintGroup; j < n_sky && j < (idx + 1u) * kPaintGroup; ++j) {
+                const uint32_t e = sky_list[j];
+                const uint32_t bx = e & 0xFFFFu, by = e >> 16;
+                const uint32_t x = bx * 8u + (lane & 7u), y = tile_y0(P, by) + (lane >> 3);
+                if (x < P.width && y < P.y1) {
+                    const size_t i_band = (size_t)(by * 8u + (lane >> 3)) * P.width + x;
+                    if constexpr (!COUNT) {
+                        // render.rs:316-322: pixel i == width is never painted
+                        if (P.out) P.out[i_band] = ((size_t)y * P.width + x == (size_t)P.width) ? 0u : P.sky;
+                    }
+                    if constexpr (DBG) {
+                        if (P.hit_cube) P.hit_cube[i_band] = kNoHit;
+                        if (P.hit_sphere) P.hit_sphere[i_band] = kNoHit;
+                        if (P.tree_hash) P.tree_hash[i_band] = px_hash;
+                    }
+                    if constexpr (COUNT) {  // one nearest-hit walk of the (empty) sphere list, one of the cube list
+                        cnt.v[0] += 2ull; cnt.v[5] += 2ull;
+                        cnt.v[2] += P.n_cubes; cnt.v[7] += P.n_cubes;
+                    }
+                }
+            }
+            painted = true;
+        }
     }
+    if (!painted) {
     const float width = (float)P.width, height = (float)P.height;
     const float aspect = width / height;
     const V3 right = v3(P.right[0], P.right[1], P.right[2]);
     const V3 up = v3(P.up[0], P.up[1], P.up[2]);
     const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
     const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
-    {
         const uint32_t bx = entry & 0xFFFFu, by = entry >> 16;
         const uint32_t ty0 = tile_y0(P, by);
         const uint32_t x = bx * 8u + (lane & 7u);
@@ -1119,22 +1115,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
         PROF_DECL
         const bool active = (x < P.width) && (y < P.y1);  // lanes outside the frame stay in the wave, inactive
 
-        float sx = (2.0f * (float)x) / width - 1.0f;
-        const float sy = -(2.0f * (float)y) / height + 1.0f;
-        sx = sx * aspect;
-        const V3 v = vnormalize(v3(sx, sy, -1.0f));
-        // camera.rs:38-40: v.x*right + v.y*up - v.z*forward, normalised
-        const V3 dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));
-        PROF_MARK(PH_RAYGEN);
-
         // render.rs:298-312: a spheres-only pass with ambient 1, a cubes-only pass with ambient_light; the
         // sphere colour wins unless it equals the sky colour.  Passes that cannot hit anything are not
         // traced (wave-uniform): no spheres at all, or no cube projecting into the tile.
+        const bool skip_s = (P.n_spheres == 0u);
+        const bool skip_c = tile_has_no_cubes(P, bx, ty0);
+        V3 dir = v3(0.0f, 0.0f, 0.0f);
+        if (!(skip_s && skip_c)) {
+            float sx = (2.0f * (float)x) / width - 1.0f;
+            const float sy = -(2.0f * (float)y) / height + 1.0f;
+            sx = sx * aspect;
+            const V3 v = vnormalize(v3(sx, sy, -1.0f));
+            // camera.rs:38-40: v.x*right + v.y*up - v.z*forward, normalised
+            dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));
+        }
+        PROF_MARK(PH_RAYGEN);
         uint32_t px = 0u, hs = 0u, hc = 0u, hit_s = kNoHit, hit_c = kNoHit;
-        const bool no_cubes = tile_has_no_cubes(P, bx, ty0);
         for (uint32_t pass = PASS_SPHERES; pass <= PASS_CUBES; ++pass) {
             uint32_t hh, hi, c;
-            const bool skip = (pass == PASS_SPHERES) ? (P.n_spheres == 0u) : no_cubes;
+            const bool skip = (pass == PASS_SPHERES) ? skip_s : skip_c;
             if (skip) {
                 c = P.sky;
                 hi = kNoHit;
@@ -1261,13 +1260,10 @@ int launch_queue(const Params& p, int variant, void* stream)
 {
     const uint32_t tiles = p.grid_tx * p.grid_ty;
     if (tiles == 0u) return (int)hipSuccess;
-    dim3 grid((tiles + 255u) / 256u, 1u, 1u), block(256u, 1u, 1u);
+    dim3 grid((tiles + 1023u) / 1024u, 1u, 1u), block(1024u, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
-    switch (variant) {
-    case kVariantDebug: hipLaunchKernelGGL((build_queue<true, false>), grid, block, 0, s, p); break;
-    case kVariantCount: hipLaunchKernelGGL((build_queue<false, true>), grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL((build_queue<false, false>), grid, block, 0, s, p); break;
-    }
+    (void)variant;
+    hipLaunchKernelGGL(build_queue, grid, block, 0, s, p);
     return (int)hipGetLastError();
 }
 
@@ -1275,7 +1271,9 @@ int launch_render(const Params& p, int variant, void* stream)
 {
     const uint32_t tiles = p.grid_tx * p.grid_ty;
     if (tiles == 0u) return (int)hipSuccess;
-    dim3 grid(tiles, 1u, 1u), block(64u, 1u, 1u);  // single-wave workgroups; those beyond the queue's length exit at once
+    // single-wave workgroups: one per traced tile, then one per kPaintGroup painted tiles; the split is
+    // only known on the device, so the grid covers both extremes and the surplus exits at once
+    dim3 grid(tiles + (tiles + kPaintGroup - 1u) / kPaintGroup, 1u, 1u), block(64u, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
     case kVariantDebug: hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, s, p); break;
