@@ -229,6 +229,12 @@ int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches);
 /* Toggle HIP-event timing of rt_render_device launches (off by default). */
 int rt_enable_timing(rt_ctx* ctx, int enable);
 
+/* Diagnostic, no counterpart in the reference: runs about n_cases pseudo-random f32 divisions on the
+ * device, once through the kernels' shared-reciprocal sequence and once through the compiler's IEEE
+ * division, and reports how many results differ in any bit (must be 0: the kernels' claim of
+ * reference-identical rounding of normalize() and of the slab quotients rests on it). */
+int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t* out_mismatches, uint64_t* out_cases);
+
 /* Raw HIP stream of the context as an opaque pointer (hipStream_t), for hosts that order their
  * own work (e.g. an RCCL gather) after the render.  No reference counterpart. */
 int rt_get_stream(rt_ctx* ctx, void** out_hip_stream);

@@ -198,6 +198,12 @@ class Context:
         self._check(self._lib.rt_count_rays_part(self._ctx, C.byref(frame), n_parts, part, C.byref(c)))
         return c
 
+    def selftest_division(self, n_cases, seed=1):
+        """(mismatches, cases) of the device's shared-reciprocal division against its IEEE division."""
+        bad, n = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rt_selftest_division(self._ctx, seed, n_cases, C.byref(bad), C.byref(n)))
+        return bad.value, n.value
+
     def enable_timing(self, on=True):
         self._check(self._lib.rt_enable_timing(self._ctx, 1 if on else 0))
 

@@ -574,6 +574,25 @@ int rt_count_rays_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     return RT_OK;
 }
 
+int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t* out_mismatches, uint64_t* out_cases)
+{
+    if (!ctx || !out_mismatches || !out_cases) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t iters = 4096u;
+    uint64_t blocks64 = (n_cases + 256ull * iters - 1ull) / (256ull * iters);
+    if (blocks64 == 0) blocks64 = 1;
+    if (blocks64 > 65536ull) return fail(ctx, RT_ERR_LIMIT, "rt_selftest_division: at most 2^36 cases per call");
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    hipError_t e = (hipError_t)launch_selftest_division(seed, (uint32_t)blocks64, iters, ctx->d_counters, (void*)ctx->stream);
+    if (e != hipSuccess) return fail_hip(ctx, e, "selftest kernel launch");
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out_mismatches = h[0];
+    *out_cases = h[1];
+    return RT_OK;
+}
+
 int rt_enable_timing(rt_ctx* ctx, int enable)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");

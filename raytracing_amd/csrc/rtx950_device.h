@@ -127,5 +127,7 @@ enum KernelVariant { kVariantRender = 0, kVariantDebug = 1, kVariantCount = 2 };
 int launch_queue(const Params& p, int variant, void* stream);
 int launch_render(const Params& p, int variant, void* stream);
 int launch_classify(const TileParams& t, void* stream);
+// selftest_division: blocks x 256 threads x iters operand pairs; d_out[0] += mismatches, d_out[1] += cases
+int launch_selftest_division(uint32_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out, void* stream);
 
 }  // namespace rtx950

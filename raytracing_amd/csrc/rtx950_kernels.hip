@@ -95,6 +95,33 @@ DEV V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 DEV V3 vneg(V3 a) { return v3(-a.x, -a.y, -a.z); }
 DEV V3 vscale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 DEV float vdot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// ---- correctly rounded a / d for several numerators over one denominator
+// hipcc expands an IEEE f32 division into v_div_scale x2, v_rcp_f32, this chain and v_div_fixup:
+//     e = fma(-d, r0, 1)   r = fma(e, r0, r0)              (one Newton step on r0 = v_rcp_f32(d))
+//     q0 = a r   q1 = fma(fma(-d, q0, a), r, q0)   q = fma(fma(-d, q1, a), r, q1)
+// v_div_scale / v_div_fixup only act on operands near the ends of the exponent range, on zeros,
+// infinities and NaN.  For d and a of magnitude in [2^-60, 2^60] (a may also be +-0) the chain alone
+// IS the compiled division, bit for bit (rt_selftest_division checks that on the device), and r can
+// be shared by every numerator over the same d.  Operands outside that range take the plain `/`.
+DEV bool div_in_range(float v)
+{
+    const float a = __builtin_fabsf(v);
+    return a >= 0x1p-60f && a <= 0x1p60f;
+}
+DEV bool num_in_range(float v) { return v == 0.0f || div_in_range(v); }
+DEV float rcp_refined(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+DEV float div_shared(float a, float d, float r)
+{
+    const float q0 = a * r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, a), r, q0);
+    const float q2 = __builtin_fmaf(__builtin_fmaf(-d, q1, a), r, q1);
+    return (a == 0.0f) ? q0 : q2;  // +-0 / d keeps the sign rule of the product
+}
 DEV V3 vnormalize(V3 a)
 {
     float n = __builtin_sqrtf(vdot(a, a));
@@ -172,6 +199,7 @@ struct RayPre {
     bool unsafe;              // outside the ranges the error analysis assumes: always evaluated exactly
     uint32_t zbits;           // safe rays only: bit c set = direction component c is exactly zero
     float zdelta;             // margin of zero_axis_check
+    bool div_ok;              // operands of the slab quotients are in div_shared's range (cube_distance)
     bool wild;                // non-finite or huge components: even the wave-level cull keeps every cube
 };
 
@@ -218,6 +246,7 @@ DEV RayPre ray_pre(const Params& P, V3 o, V3 d)
     // 2^-20 (B + |o|) = 16 ulp of the largest magnitude involved: RN(k -+ h), RN(k - o) and the
     // reference's RN(bound - o) each err by at most one
     q.zdelta = 0x1p-20f * (P.bound_max + bigo);
+    q.div_ok = safe && !(zx || zy || zz);
     // The cull (cull_test) has no division, so zero or tiny direction components are fine there: a ray
     // whose exact line misses a box by the slack margin is rejected by the reference too, also through
     // its +-inf arithmetic (cube.rs:90-113 with d_c = 0: both t of that axis are the same infinity, and
@@ -291,6 +320,32 @@ DEV bool cube_exact(const CubeRec& c, V3 o, V3 d, float& distance)
     return true;
 }
 
+// The distance of cube_exact for a cube that is known to pass the slab test, for a ray whose operands
+// are in the range of div_shared (div_ok: a "safe" ray, see ray_pre, without zero direction components:
+// |d_c| in [2^-40, 2^40], and every bound - o_c is 0 or of magnitude in [2^-53, 2^21], being a difference
+// of two floats that are 0 or in [2^-30, 2^20]).  Same six quotients, same staging; the two quotients of
+// an axis share one refined reciprocal.  Other lanes take cube_exact.
+DEV float cube_distance(const CubeRec& c, V3 o, V3 d, bool div_ok)
+{
+    const float rx = rcp_refined(d.x), ry = rcp_refined(d.y), rz = rcp_refined(d.z);
+    const float t0x = div_shared(c.minx - o.x, d.x, rx), t1x = div_shared(c.maxx - o.x, d.x, rx);
+    const float t0y = div_shared(c.miny - o.y, d.y, ry), t1y = div_shared(c.maxy - o.y, d.y, ry);
+    const float t0z = div_shared(c.minz - o.z, d.z, rz), t1z = div_shared(c.maxz - o.z, d.z, rz);
+    const bool sx = t0x < t1x, sy = t0y < t1y, sz = t0z < t1z;
+    float tmin = sx ? t0x : t1x, tmax = sx ? t1x : t0x;
+    tmin = __builtin_fmaxf(tmin, sy ? t0y : t1y);
+    tmax = __builtin_fminf(tmax, sy ? t1y : t0y);
+    tmin = __builtin_fmaxf(tmin, sz ? t0z : t1z);
+    tmax = __builtin_fminf(tmax, sz ? t1z : t0z);
+    float distance = (tmin < 0.0f) ? tmax : tmin;
+    if (__builtin_amdgcn_ballot_w64(!div_ok) != 0ull) {
+        float e = 0.0f;
+        (void)cube_exact(c, o, d, e);
+        distance = div_ok ? distance : e;
+    }
+    return distance;
+}
+
 // reference src/sphere.rs:25-39 (hit test and distance)
 DEV bool sphere_exact(const SphereRec& s, V3 o, V3 d, float& distance)
 {
@@ -319,11 +374,10 @@ struct Hit {
 
 // reference src/cube.rs:146-204, evaluated for the winning cube only (the reference evaluates it for
 // every slab-passing candidate and throws the losers away)
-DEV Hit cube_resolve(const Params& P, uint32_t idx, V3 o, V3 d)
+DEV Hit cube_resolve(const Params& P, uint32_t idx, V3 o, V3 d, bool div_ok)
 {
     const CubeRec c = P.cubes[idx];  // per-lane gather: lanes may have different winners
-    float distance = 0.0f;
-    (void)cube_exact(c, o, d, distance);  // the winner's reference distance (cube.rs:90-145), once per ray
+    const float distance = cube_distance(c, o, d, div_ok);  // the winner's reference distance (cube.rs:90-145), once per ray
     Hit h;
     h.p = vadd(o, vscale(d, distance));
     h.n = v3(0.0f, 0.0f, 0.0f);
@@ -580,6 +634,7 @@ struct QState {
     bool done;          // Q_SHADOW: first cube in array order whose exact test passes
     uint32_t blocker;
     float tol;          // the ray's 2E (out)
+    bool div_ok;        // the ray's RayPre::div_ok (out)
 };
 
 // One pass over the cube list for the whole wave.
@@ -685,6 +740,7 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
     if (P.n_cubes == 0u) return;
     const RayPre q = ray_pre(P, o, d);
     st.tol = q.tol;
+    st.div_ok = q.div_ok;
     const CullPre cp = cull_pre(P, active, o, d, q.wild);
     cube_query_group<MODE>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
 }
@@ -692,15 +748,17 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
 // ---------------------------------------------------------------- nearest hit (render.rs:87-101)
 // `pass` is wave-uniform: PASS_SPHERES walks the sphere list, PASS_CUBES the cube list.
 template <bool COUNT>
-DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3 d, Counters& cnt PROF_ARG)
+DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3 d, bool& div_ok, Counters& cnt PROF_ARG)
 {
     uint32_t best_idx = kNoHit;
+    div_ok = false;
     if (pass == PASS_CUBES) {
         QState st;
         st.b1 = __builtin_inff(); st.b2 = __builtin_inff(); st.i1 = kNoHit;
-        st.best = __builtin_inff(); st.best_i = kNoHit; st.done = false; st.blocker = kNoHit; st.tol = 0.0f;
+        st.best = __builtin_inff(); st.best_i = kNoHit; st.done = false; st.blocker = kNoHit; st.tol = 0.0f; st.div_ok = false;
         cube_query<Q_NEAREST>(P, active, o, d, 0u, st PROF_PASS);
         best_idx = active ? st.i1 : kNoHit;
+        div_ok = st.div_ok;
         // contested: a second candidate within 2E of the best (exact duplicates, shared edges).  NaN -> contested.
         const bool contested = active && (st.i1 != kNoHit) && !(st.b2 - st.b1 > st.tol);
         if (wave_any(contested)) {
@@ -738,15 +796,13 @@ DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V
     if (pass == PASS_CUBES) {
         QState st;
         st.b1 = 0.0f; st.b2 = 0.0f; st.i1 = kNoHit; st.best = 0.0f; st.best_i = kNoHit;
-        st.done = false; st.blocker = kNoHit; st.tol = 0.0f;
+        st.done = false; st.blocker = kNoHit; st.tol = 0.0f; st.div_ok = false;
         cube_query<Q_SHADOW>(P, active, origin, dir, impact_id, st PROF_PASS);
         blocker = (active && st.done) ? st.blocker : kNoHit;
         if (wave_any(blocker != kNoHit)) {
             // the blocker's exact distance (per-lane gather; the loop only proved that it passes)
             const CubeRec c = P.cubes[blocker != kNoHit ? blocker : 0u];
-            float ed = 0.0f;
-            (void)cube_exact(c, origin, dir, ed);
-            sdist = ed;
+            sdist = cube_distance(c, origin, dir, st.div_ok);
         }
         if constexpr (COUNT) {
             // executed tests = cubes up to and including the blocker whose id differs from the impact id
@@ -844,7 +900,8 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
             Counters cnt = {0u, 0u, 0u, 0u, 0u};
             PROF_MARK(PH_OTHER);
             PROF_KIND(depth * 2u);
-            const uint32_t idx = nearest_query<COUNT>(P, pass, act, o, d, cnt PROF_PASS);
+            bool div_ok;
+            const uint32_t idx = nearest_query<COUNT>(P, pass, act, o, d, div_ok, cnt PROF_PASS);
             if (depth == 0u) hit_idx = idx;
             uint32_t h = hmix(kHashBasis, idx);
             const bool hit_any = act && (idx != kNoHit);
@@ -856,7 +913,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                 const uint32_t sidx = hit_any ? idx : 0u;  // lanes without a hit shade object 0 and discard the result
                 if constexpr (COUNT) cnt.shaded_hits += hit_any ? 1u : 0u;
                 Hit hit;
-                if (pass == PASS_CUBES) hit = cube_resolve(P, sidx, o, d);
+                if (pass == PASS_CUBES) hit = cube_resolve(P, sidx, o, d, div_ok);
                 else hit = sphere_resolve(P, sidx, o, d);
                 const MatRec m = P.mats[hit.material];
                 PROF_MARK(PH_RESOLVE);
@@ -1101,12 +1158,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
         }
     }
     if (!painted) {
-    const float width = (float)P.width, height = (float)P.height;
-    const float aspect = width / height;
-    const V3 right = v3(P.right[0], P.right[1], P.right[2]);
-    const V3 up = v3(P.up[0], P.up[1], P.up[2]);
-    const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
-    const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
+        const float width = (float)P.width, height = (float)P.height;
+        const float aspect = width / height;
+        const V3 right = v3(P.right[0], P.right[1], P.right[2]);
+        const V3 up = v3(P.up[0], P.up[1], P.up[2]);
+        const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
+        const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
         const uint32_t bx = entry & 0xFFFFu, by = entry >> 16;
         const uint32_t ty0 = tile_y0(P, by);
         const uint32_t x = bx * 8u + (lane & 7u);
@@ -1247,7 +1304,49 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
     }
 }
 
+// ---------------------------------------------------------------- rt_selftest_division
+// Device check of the claim under "correctly rounded a / d": for pseudo-random operands that cover the
+// whole in-range exponent span, special significands and zero numerators, div_shared == the compiled
+// `/`, bit for bit.  out[0] += mismatches, out[1] += cases.
+__global__ __launch_bounds__(256) void selftest_division(uint32_t seed, uint32_t iters, unsigned long long* out)
+{
+    uint32_t s = seed ^ ((blockIdx.x * 256u + threadIdx.x) * 2654435761u) ^ 0x9E3779B9u;
+    unsigned long long bad = 0ull, cases = 0ull;
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint32_t w[4];
+        for (int k = 0; k < 4; ++k) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; w[k] = s; }
+        // significands: random, or (1 in 8) one of the hard shapes: all ones, 1.0, 1.0 + ulp, all ones - 1
+        auto mant = [](uint32_t r) -> uint32_t {
+            const uint32_t m = r & 0x7FFFFFu;
+            switch ((r >> 23) & 31u) {
+            case 0: return 0x7FFFFFu;
+            case 1: return 0u;
+            case 2: return 1u;
+            case 3: return 0x7FFFFEu;
+            default: return m;
+            }
+        };
+        const uint32_t ed = 127u - 60u + (w[2] % 121u), ea = 127u - 60u + ((w[2] >> 8) % 121u);  // exponents -60..60
+        const float d = __builtin_bit_cast(float, ((w[2] >> 31) << 31) | (ed << 23) | mant(w[0]));
+        float a = __builtin_bit_cast(float, ((w[3] >> 31) << 31) | (ea << 23) | mant(w[1]));
+        if (((w[3] >> 8) & 63u) == 0u) a = (w[3] & 1u) ? 0.0f : -0.0f;
+        if (!(div_in_range(d) && num_in_range(a))) continue;  // 2^60 with a non-zero significand is out of range
+        const float fast = div_shared(a, d, rcp_refined(d));
+        const float ref = a / d;
+        ++cases;
+        if (__builtin_bit_cast(uint32_t, fast) != __builtin_bit_cast(uint32_t, ref)) ++bad;
+    }
+    for (int off = 32; off > 0; off >>= 1) { bad += __shfl_down(bad, off, 64); cases += __shfl_down(cases, off, 64); }
+    if ((threadIdx.x & 63u) == 0u) { atomicAdd(&out[0], bad); atomicAdd(&out[1], cases); }
+}
+
 }  // namespace
+
+int launch_selftest_division(uint32_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out, void* stream)
+{
+    hipLaunchKernelGGL(selftest_division, dim3(blocks, 1u, 1u), dim3(256u, 1u, 1u), 0, (hipStream_t)stream, seed, iters, d_out);
+    return (int)hipGetLastError();
+}
 
 int launch_classify(const TileParams& t, void* stream)
 {

@@ -215,3 +215,11 @@ def test_degenerate_cubes(gpu_ctx, oracle_mod, default_scene):
         f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, w, h)
         assert_parity(gfb, gpl, ofb, opl, f"degenerate cubes {w}x{h}")
         assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+
+
+def test_shared_reciprocal_division_is_ieee(gpu_ctx):
+    """The kernels divide several numerators by one denominator with a shared refined reciprocal; on the
+    device that must equal the compiler's IEEE division in every bit (2^32 pseudo-random cases)."""
+    for seed in (1, 2):
+        bad, n = gpu_ctx.selftest_division(1 << 31, seed=seed)
+        assert n > (1 << 30) and bad == 0, (bad, n)
