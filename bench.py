@@ -43,39 +43,56 @@ def algorithmic_flops(c, n_lights):
     return 26.0 * c.cube_tests + 25.0 * c.sphere_tests + 60.0 * n_lights * c.shaded_hits
 
 
+def traffic_from_profile(workload):
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/traffic.json, written by tools/summarize_pmc.py: 2 x FETCH_SIZE KB + WRITE_SIZE KB
+    as MI355X_MICROARCH.md prescribes for gfx950); None when no pass is on file for the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        return t.get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def make_scene(rt, kind, kwargs):
     return rt.default_scene(**kwargs) if kind == "default" else rt.synthetic_scene(**kwargs)
 
 
 def cpu_baseline(scene, width, height, target_s, max_threads):
-    """Reference algorithm on the host (oracle, literal mode) over rows 0, step, 2*step, ... of the frame."""
+    """Reference algorithm on the host (oracle, literal mode = per-light re-casting like the reference):
+    whole frames of the same workload, repeated until about target_s seconds of CPU work are done.  A
+    frame that alone would take longer than target_s is sampled by rows 0, step, 2*step, ... instead."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     O = orc.OracleScene(scene)
     frame = scene.frame(width, height)
     threads = max(1, min(max_threads, len(os.sched_getaffinity(0))))
-    step = max(1, height // 24)
+    probe_step = max(1, height // 24)
     t0 = time.perf_counter()
-    _, _, cnt, used = O.render(frame, reuse_secondary=False, row_step=step, threads=threads)
+    _, _, cnt, used = O.render(frame, reuse_secondary=False, row_step=probe_step, threads=threads)
     t_probe = time.perf_counter() - t0
-    # scale the sample so that it takes about target_s seconds
-    want_rows = max(1.0, (height / step) * (target_s / max(t_probe, 1e-3)))
-    step2 = max(1, int(round(height / min(want_rows, height))))
-    if step2 != step:
+    est_frame = t_probe * probe_step  # seconds for a whole frame
+    step = max(1, int(round(est_frame / target_s))) if est_frame > target_s else 1
+    rays, secs, frames = 0, 0.0, 0
+    while True:
         t0 = time.perf_counter()
-        _, _, cnt, used = O.render(frame, reuse_secondary=False, row_step=step2, threads=threads)
-        t_probe = time.perf_counter() - t0
-        step = step2
-    rays = cnt.nearest_rays + cnt.shadow_rays  # literal mode: what the reference casts
+        _, _, cnt, used = O.render(frame, reuse_secondary=False, row_step=step, threads=threads)
+        secs += time.perf_counter() - t0
+        rays += cnt.nearest_rays + cnt.shadow_rays  # literal mode: what the reference casts
+        frames += 1
+        if secs >= 0.85 * target_s or frames >= 64:
+            break
     n_rows = (height + step - 1) // step
+    what = f"{frames} x the whole {width}x{height} frame" if step == 1 else \
+           f"{frames} x rows 0::{step} ({n_rows} of {height} rows) of the {width}x{height} frame"
     return {
-        "value": rays / t_probe / 1e6,
+        "value": rays / secs / 1e6,
         "unit": "Mrays/s",
         "cores": int(used),
         "kind": "port",
-        "sample": f"rows 0::{step} ({n_rows} of {height} rows, {rays} reference rays) of the {width}x{height} frame, "
-                  f"{t_probe:.2f} s, oracle literal mode (per-light re-casting), pthreads over rows",
-        "seconds": t_probe,
+        "sample": f"{what}: {rays} reference rays in {secs:.2f} s, oracle literal mode (per-light re-casting), pthreads over rows",
+        "seconds": secs,
     }
 
 
@@ -85,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="minecraft_4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target size of the CPU baseline sample; 0 disables it")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU baseline sample; 0 disables it")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
     args = ap.parse_args()
@@ -199,7 +216,7 @@ def main():
             },
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": None,
+                "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic_from_profile(args.workload),
                 "kernel": "render_kernel<false,false>", "kernel_avg_ms": kern_ms, "launches_timed": kern_n,
                 "algorithmic_flops_per_launch": flops_launch,
                 "frac_of_nonfma_lane_op_ceiling": achieved_tf / PEAK_LANE_OPS_T,
