@@ -246,7 +246,8 @@ int prepare(rt_ctx* ctx, Params& p)
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 16 * sizeof(uint32_t), ctx->stream));
         return RT_OK;
     }
-    const size_t words = kStampBase + (size_t)p.tiles_x * p.tiles_y;
+    // fine stamps per 8x8 tile, then coarse stamps per block of 8x8 tiles
+    const size_t words = kStampBase + (size_t)p.tiles_x * p.tiles_y + (size_t)((p.tiles_x + 7u) / 8u) * ((p.tiles_y + 7u) / 8u);
     if (ctx->stamps_cap < words) {
         if (ctx->d_stamps) HIP_TRY(ctx, hipFree(ctx->d_stamps));
         ctx->d_stamps = nullptr;

@@ -74,7 +74,8 @@ struct Params {
     uint32_t n_parts, part;  // 16-row blocks b with b % n_parts == part are rendered, output compact
     // Tile stamps written by classify_tiles for this frame (null: every tile is traced).  Word 0 ==
     // frame_id: some cube could not be projected, trace every tile; word 64 + ty*tiles_x + tx ==
-    // frame_id: some cube's padded projection touches the 8x8 pixel tile (tx, ty) of the frame.
+    // frame_id: some cube's padded projection touches the 8x8 pixel tile (tx, ty) of the frame.  After the
+    // tiles_x * tiles_y fine words: one coarse word per block of 8x8 tiles, used by large projections.
     const uint32_t* tile_stamps;
     uint32_t tiles_x, tiles_y;
     uint32_t frame_id;

@@ -1058,7 +1058,11 @@ DEV bool tile_has_no_cubes(const Params& P, uint32_t bx, uint32_t ty0)
     const uint32_t r1 = ((ty0 + 7u) >> 3) < last ? ((ty0 + 7u) >> 3) : last;
     const uint32_t* st = P.tile_stamps;
     const uint32_t s_all = st[0], s0 = st[kStampBase + r0 * P.tiles_x + bx], s1 = st[kStampBase + r1 * P.tiles_x + bx];
-    return (s_all != P.frame_id) && (s0 != P.frame_id) && (s1 != P.frame_id);
+    // coarse level: blocks of 8x8 tiles, stamped instead of the tiles by cubes with a large projection
+    const uint32_t* cs = st + kStampBase + P.tiles_x * P.tiles_y;
+    const uint32_t ctx = (P.tiles_x + 7u) >> 3;
+    const uint32_t c0 = cs[(r0 >> 3) * ctx + (bx >> 3)], c1 = cs[(r1 >> 3) * ctx + (bx >> 3)];
+    return (s_all != P.frame_id) && (s0 != P.frame_id) && (s1 != P.frame_id) && (c0 != P.frame_id) && (c1 != P.frame_id);
 }
 
 // build_queue: one thread per tile of the launch appends the tile to one of the queue's lists.  A
@@ -1298,9 +1302,17 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
     const uint32_t py1 = fy1 > (double)T.height - 1.0 ? T.height - 1u : (uint32_t)fy1;
     const uint32_t tx0 = px0 >> 3, tx1 = px1 >> 3, ty0 = py0 >> 3, ty1 = py1 >> 3;  // < tiles_x, < tiles_y
     const uint32_t nx = tx1 - tx0 + 1u, n = nx * (ty1 - ty0 + 1u);
-    for (uint32_t i = lane; i < n; i += 64u) {
-        const uint32_t tx = tx0 + i % nx, ty = ty0 + i / nx;
-        T.stamps[kStampBase + (size_t)ty * T.tiles_x + tx] = T.frame_id;
+    if (n <= 1024u) {
+        for (uint32_t i = lane; i < n; i += 64u) {
+            const uint32_t tx = tx0 + i % nx, ty = ty0 + i / nx;
+            T.stamps[kStampBase + (size_t)ty * T.tiles_x + tx] = T.frame_id;
+        }
+    } else {
+        // a large projection (a cube near the eye): stamp blocks of 8x8 tiles instead, 64x fewer stores
+        uint32_t* cs = T.stamps + kStampBase + (size_t)T.tiles_x * T.tiles_y;
+        const uint32_t ctx = (T.tiles_x + 7u) >> 3;
+        const uint32_t cx0 = tx0 >> 3, cy0 = ty0 >> 3, cnx = (tx1 >> 3) - cx0 + 1u, cn = cnx * ((ty1 >> 3) - cy0 + 1u);
+        for (uint32_t i = lane; i < cn; i += 64u) cs[(size_t)(cy0 + i / cnx) * ctx + cx0 + i % cnx] = T.frame_id;
     }
 }
 
