@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -30,6 +31,10 @@ struct rt_ctx {
     CubeRec* d_cubes = nullptr;
     float* d_cube_filt = nullptr;
     uint32_t* d_cube_id = nullptr;
+    uint32_t* d_cube_perm = nullptr;
+    BvhNode* d_bvh = nullptr;
+    uint32_t* d_bvh_items = nullptr;
+    float* d_chunk_box = nullptr;
     uint32_t* d_cube_mat = nullptr;
     SphereRec* d_spheres = nullptr;
     SphereMeta* d_sphere_meta = nullptr;
@@ -66,6 +71,8 @@ constexpr size_t kCounterBytes = 256 + kProfWaves * 40 * sizeof(uint32_t);
 #else
 constexpr size_t kCounterBytes = 32 * sizeof(unsigned long long);
 #endif
+
+constexpr size_t kSmallListMax = 256;  // cube lists up to this length are streamed in list order without chunk boxes
 
 thread_local std::string g_tls_err;
 
@@ -107,6 +114,14 @@ void free_scene(rt_ctx* c)
     c->d_cube_filt = nullptr;
     (void)hipFree(c->d_cube_id);
     c->d_cube_id = nullptr;
+    (void)hipFree(c->d_cube_perm);
+    c->d_cube_perm = nullptr;
+    (void)hipFree(c->d_bvh);
+    c->d_bvh = nullptr;
+    (void)hipFree(c->d_bvh_items);
+    c->d_bvh_items = nullptr;
+    (void)hipFree(c->d_chunk_box);
+    c->d_chunk_box = nullptr;
     (void)hipFree(c->d_cube_mat);
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_sphere_meta);
@@ -361,7 +376,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
     if ((n_cubes && !cubes) || (n_spheres && !spheres)) return fail(ctx, RT_ERR_INVALID_ARG, "object array is null");
     if (!materials || n_materials == 0) return fail(ctx, RT_ERR_INVALID_ARG, "material table is empty");
-    if (n_cubes > 0x7FFFFFFFu || n_spheres > 0x7FFFFFFFu) return fail(ctx, RT_ERR_UNSUPPORTED, "too many objects");
+    if (n_cubes > 0x0FFFFFFFu || n_spheres > 0x7FFFFFFFu) return fail(ctx, RT_ERR_UNSUPPORTED, "too many objects");
     if (n_textures && (!atlas_rgb8 || tex_w == 0 || tex_h == 0 || sprite == 0)) return fail(ctx, RT_ERR_INVALID_ARG, "bad atlas description");
     if (n_textures && ((uint64_t)n_textures * tex_w * tex_h > 0x3FFFFFFFull)) return fail(ctx, RT_ERR_UNSUPPORTED, "atlas too large");
     for (size_t i = 0; i < n_materials; ++i) {
@@ -379,13 +394,6 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
 
     std::vector<CubeRec> hc(n_cubes);
     std::vector<uint32_t> hcm(n_cubes);
-    // cull stream, padded to a multiple of 64 records (one per lane) with far-away zero-size boxes
-    const size_t n_filt = ((n_cubes + 63) / 64) * 64 + 64;
-    std::vector<uint32_t> hid(n_filt, 0u);
-    std::vector<float> hf(n_filt * 4);
-    for (size_t i = 0; i < n_filt; ++i) {
-        hf[4 * i + 0] = 1e18f; hf[4 * i + 1] = -1e18f; hf[4 * i + 2] = 1e18f; hf[4 * i + 3] = 0.0f;
-    }
     float bmax = 0.0f;
     bool fast_ok = true;
     auto check_bound = [&](float b) {
@@ -402,11 +410,151 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
         r.id = cubes[i].id;
         r.size = cubes[i].size;
         hcm[i] = cubes[i].material;
-        hf[4 * i + 0] = cubes[i].center.x; hf[4 * i + 1] = cubes[i].center.y; hf[4 * i + 2] = cubes[i].center.z;
-        hf[4 * i + 3] = std::fabs(half);  // min > max (negative size) is the same box to the slab test (lib.rs:29-35 sorts the two t)
-        hid[i] = cubes[i].id;
         check_bound(r.minx); check_bound(r.maxx); check_bound(r.miny);
         check_bound(r.maxy); check_bound(r.minz); check_bound(r.maxz);
+    }
+    // Cull stream, padded to a multiple of 64 records (one per lane) with far-away zero-size boxes.  A
+    // short list is streamed in list order.  A long one is streamed in Morton order of the cube centres,
+    // with the list index of every record (cube_perm) and a bounding box per chunk of 64 (chunk_box).
+    const size_t n_filt = ((n_cubes + 63) / 64) * 64 + 64;
+    const bool large = n_cubes > kSmallListMax;
+    std::vector<uint32_t> perm(n_filt, 0u);
+    for (size_t i = 0; i < n_cubes; ++i) perm[i] = (uint32_t)i;
+    if (large) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = 0; i < n_cubes; ++i) {
+            const float c[3] = {cubes[i].center.x, cubes[i].center.y, cubes[i].center.z};
+            for (int k = 0; k < 3; ++k)
+                if (std::isfinite(c[k])) { lo[k] = std::min(lo[k], (double)c[k]); hi[k] = std::max(hi[k], (double)c[k]); }
+        }
+        auto spread = [](uint32_t v) {  // 10 bits -> every third bit
+            v &= 0x3FFu;
+            v = (v | (v << 16)) & 0x030000FFu;
+            v = (v | (v << 8)) & 0x0300F00Fu;
+            v = (v | (v << 4)) & 0x030C30C3u;
+            v = (v | (v << 2)) & 0x09249249u;
+            return v;
+        };
+        std::vector<uint32_t> code(n_cubes, 0u);
+        for (size_t i = 0; i < n_cubes; ++i) {
+            const float c[3] = {cubes[i].center.x, cubes[i].center.y, cubes[i].center.z};
+            uint32_t q[3] = {0u, 0u, 0u};
+            for (int k = 0; k < 3; ++k) {
+                if (!std::isfinite(c[k]) || !(hi[k] > lo[k])) continue;
+                q[k] = (uint32_t)std::min(1023.0, std::max(0.0, ((double)c[k] - lo[k]) / (hi[k] - lo[k]) * 1023.0));
+            }
+            code[i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        }
+        std::stable_sort(perm.begin(), perm.begin() + n_cubes, [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+    }
+    std::vector<uint32_t> hid(n_filt, 0u);
+    std::vector<float> hf(n_filt * 4);
+    for (size_t j = 0; j < n_filt; ++j) {
+        hf[4 * j + 0] = 1e18f; hf[4 * j + 1] = -1e18f; hf[4 * j + 2] = 1e18f; hf[4 * j + 3] = 0.0f;
+    }
+    for (size_t j = 0; j < n_cubes; ++j) {
+        const rt_cube& c = cubes[perm[j]];
+        hf[4 * j + 0] = c.center.x; hf[4 * j + 1] = c.center.y; hf[4 * j + 2] = c.center.z;
+        hf[4 * j + 3] = std::fabs(c.size / 2.0f);  // min > max (negative size) is the same box to the slab test (lib.rs:29-35 sorts the two t)
+        hid[j] = c.id;
+    }
+    const size_t n_chunks = large ? (n_cubes + 63) / 64 : 0;
+    const size_t n_box = ((n_chunks + 63) / 64) * 64 + 64;
+    std::vector<float> hbox(n_box * 8, 0.0f);
+    for (size_t c = 0; c < n_chunks; ++c) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        bool finite = true;
+        for (size_t j = c * 64; j < std::min(n_cubes, c * 64 + 64); ++j) {
+            const CubeRec& r = hc[perm[j]];
+            const float b[3][2] = {{r.minx, r.maxx}, {r.miny, r.maxy}, {r.minz, r.maxz}};
+            for (int k = 0; k < 3; ++k)
+                for (int e = 0; e < 2; ++e) {
+                    if (!std::isfinite(b[k][e])) finite = false;
+                    lo[k] = std::min(lo[k], (double)b[k][e]); hi[k] = std::max(hi[k], (double)b[k][e]);
+                }
+        }
+        for (int k = 0; k < 3; ++k) {
+            // centre rounded to f32, half extent rounded up so that centre +- half still covers [lo, hi]
+            const float ctr = finite ? (float)((lo[k] + hi[k]) * 0.5) : 0.0f;
+            float half = finite ? (float)std::max(hi[k] - (double)ctr, (double)ctr - lo[k]) : INFINITY;
+            if (finite) half = std::nextafter(half, INFINITY);
+            hbox[8 * c + k] = ctr;
+            hbox[8 * c + 4 + k] = half;
+        }
+    }
+    // BVH for incoherent bundles: items = stream records in Morton order (a long list's stream already is)
+    std::vector<uint32_t> items(n_cubes + 1, 0u);
+    for (size_t j = 0; j < n_cubes; ++j) items[j] = (uint32_t)j;
+    if (!large && n_cubes > 1) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = 0; i < n_cubes; ++i) {
+            const float c[3] = {cubes[i].center.x, cubes[i].center.y, cubes[i].center.z};
+            for (int k = 0; k < 3; ++k)
+                if (std::isfinite(c[k])) { lo[k] = std::min(lo[k], (double)c[k]); hi[k] = std::max(hi[k], (double)c[k]); }
+        }
+        auto spread = [](uint32_t v) {
+            v &= 0x3FFu;
+            v = (v | (v << 16)) & 0x030000FFu;
+            v = (v | (v << 8)) & 0x0300F00Fu;
+            v = (v | (v << 4)) & 0x030C30C3u;
+            v = (v | (v << 2)) & 0x09249249u;
+            return v;
+        };
+        std::vector<uint32_t> code(n_cubes, 0u);
+        for (size_t i = 0; i < n_cubes; ++i) {
+            const float c[3] = {cubes[i].center.x, cubes[i].center.y, cubes[i].center.z};
+            uint32_t q[3] = {0u, 0u, 0u};
+            for (int k = 0; k < 3; ++k) {
+                if (!std::isfinite(c[k]) || !(hi[k] > lo[k])) continue;
+                q[k] = (uint32_t)std::min(1023.0, std::max(0.0, ((double)c[k] - lo[k]) / (hi[k] - lo[k]) * 1023.0));
+            }
+            code[i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        }
+        std::stable_sort(items.begin(), items.begin() + n_cubes, [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+    }
+    std::vector<BvhNode> nodes;
+    {
+        // depth-first emission (depth is log2(n)); the skip link is known when the subtree is complete
+        auto box_of = [&](size_t lo_i, size_t hi_i, BvhNode& nd) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool finite = true;
+            for (size_t j = lo_i; j < hi_i; ++j) {
+                const CubeRec& r = hc[perm[items[j]]];
+                const float b[3][2] = {{r.minx, r.maxx}, {r.miny, r.maxy}, {r.minz, r.maxz}};
+                for (int k = 0; k < 3; ++k)
+                    for (int e = 0; e < 2; ++e) {
+                        if (!std::isfinite(b[k][e])) finite = false;
+                        lo[k] = std::min(lo[k], (double)b[k][e]); hi[k] = std::max(hi[k], (double)b[k][e]);
+                    }
+            }
+            float c[3], h[3];
+            for (int k = 0; k < 3; ++k) {
+                c[k] = finite ? (float)((lo[k] + hi[k]) * 0.5) : 0.0f;
+                h[k] = finite ? std::nextafter((float)std::max(hi[k] - (double)c[k], (double)c[k] - lo[k]), INFINITY) : INFINITY;
+            }
+            nd.cx = c[0]; nd.cy = c[1]; nd.cz = c[2]; nd.hx = h[0]; nd.hy = h[1]; nd.hz = h[2];
+        };
+        std::function<void(size_t, size_t)> build = [&](size_t lo_i, size_t hi_i) {
+            const size_t me = nodes.size();
+            nodes.push_back(BvhNode{});
+            box_of(lo_i, hi_i, nodes[me]);
+            if (hi_i - lo_i <= 4) {
+                nodes[me].first_count = (uint32_t)((lo_i << 3) | (hi_i - lo_i));
+            } else {
+                nodes[me].first_count = 0u;
+                const size_t mid = (lo_i + hi_i) / 2;
+                build(lo_i, mid);
+                build(mid, hi_i);
+            }
+            nodes[me].skip = (uint32_t)nodes.size();
+        };
+        if (n_cubes > 0) build(0, n_cubes);
+    }
+    double half_sum = 0.0;
+    size_t half_n = 0;
+    for (size_t i = 0; i < n_cubes; ++i) {
+        const float h = std::fabs(cubes[i].size / 2.0f);
+        if (std::isfinite(h)) { half_sum += h; ++half_n; }
     }
     std::vector<SphereRec> hs(n_spheres);
     std::vector<SphereMeta> hsm(n_spheres);
@@ -430,6 +578,10 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     if ((rc = upload(ctx, &ctx->d_cube_mat, hcm)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_cube_filt, hf)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_cube_id, hid)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_cube_perm, perm)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_chunk_box, hbox)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_bvh, nodes)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_bvh_items, items)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_spheres, hs)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_sphere_meta, hsm)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_mats, hm)) != RT_OK) return rc;
@@ -441,6 +593,14 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.cube_mat = ctx->d_cube_mat;
     b.cube_filt = ctx->d_cube_filt;
     b.cube_id = ctx->d_cube_id;
+    b.cube_perm = ctx->d_cube_perm;
+    b.chunk_box = ctx->d_chunk_box;
+    b.n_chunks = (uint32_t)n_chunks;
+    b.bvh = ctx->d_bvh;
+    b.bvh_items = ctx->d_bvh_items;
+    b.n_bvh_nodes = (uint32_t)nodes.size();
+    b.coherent_thr = half_n ? (float)(16.0 * half_sum / (double)half_n) : 0.0f;  // 16 average half sizes (swept: 8..16 best)
+    if (const char* e = getenv("RTX950_COHERENT_SCALE")) b.coherent_thr *= (float)atof(e);  // tuning experiments
     b.spheres = ctx->d_spheres;
     b.sphere_meta = ctx->d_sphere_meta;
     b.mats = ctx->d_mats;

@@ -26,6 +26,17 @@ struct CubeRec {
 };
 static_assert(sizeof(CubeRec) == 32, "CubeRec must be one dwordx8");
 
+// Bounding-volume hierarchy over the cubes for incoherent ray bundles (cube_query_bvh): binary, built
+// over the Morton order of the cube centres, stored in depth-first order so that a traversal needs no
+// stack: after a node, go to node + 1 (its first child) if the line meets the box, else to `skip`.
+struct BvhNode {
+    float cx, cy, cz;      // box centre
+    uint32_t first_count;  // leaf: (first item << 3) | count (1..4); inner node: 0
+    float hx, hy, hz;      // half extents (rounded up)
+    uint32_t skip;         // next node when this subtree is done or missed; n_bvh_nodes = end
+};
+static_assert(sizeof(BvhNode) == 32, "BvhNode must be two dwordx4");
+
 // reference src/sphere.rs:10-15
 struct SphereRec {
     float cx, cy, cz, radius;
@@ -59,6 +70,17 @@ struct Params {
     const float* cube_filt;  // ceil64(n_cubes) x (centre.x, centre.y, centre.z, half size): lane j of a wave loads record base+j
     const uint32_t* cube_id; // ceil64(n_cubes) x id (shadow exclusion, reference src/render.rs:113)
     const uint32_t* cube_mat;
+    // long lists only (n_chunks > 0): the cull stream (cube_filt, cube_id) is in Morton order, cube_perm[j]
+    // is the list index of stream record j, chunk_box holds ceil64(n_chunks) x 32 B (centre.xyz, -, half
+    // extents.xyz, -): the bounding box of the 64 cubes of a chunk
+    const uint32_t* cube_perm;
+    const float* chunk_box;
+    uint32_t n_chunks;
+    // every scene: cube_perm is valid (identity for short lists); bvh_items[k] = stream record of leaf item k
+    const BvhNode* bvh;
+    const uint32_t* bvh_items;
+    uint32_t n_bvh_nodes;
+    float coherent_thr;  // a wave whose cull inflation (2 B dr + wr) exceeds this walks the BVH per lane
     const SphereRec* spheres;
     const SphereMeta* sphere_meta;
     const MatRec* mats;

@@ -577,6 +577,7 @@ struct CullPre {  // wave-uniform
     float wr;                   // same for the moment, plus rounding slack
     float wr_raw;               // ... without the slack
     float sxy, syz, szx;        // upper bounds of |d_i| + |d_j|
+    float ax, ay, az;           // upper bounds of |d_i|
     bool all;                   // some active ray is non-finite or huge: keep every cube
 };
 
@@ -599,6 +600,7 @@ DEV CullPre cull_pre(const Params& P, bool active, V3 o, V3 d, bool wild)
     const float omax = wave_max(active ? om : z);
     const float ax = __builtin_fabsf(c.dxc) + c.dr, ay = __builtin_fabsf(c.dyc) + c.dr, az = __builtin_fabsf(c.dzc) + c.dr;
     c.sxy = ax + ay; c.syz = ay + az; c.szx = az + ax;
+    c.ax = ax; c.ay = ay; c.az = az;
     // Rounding slack.  Sources (u = 2^-24, B = largest bound magnitude, O = omax, D = ax+ay+az >= |d_c|):
     //   this test's own fma chains and the per-lane moments      <= ~12 u (B + O) D
     //   the reference's rounded t values vs exact arithmetic      <= ~12 u (B + O) D   (see cube_slab_approx)
@@ -631,21 +633,81 @@ struct QState {
     uint32_t i1;        //            ... and the cube index of the smallest
     float best;         // Q_NEAREST_EXACT: the reference's fold (render.rs:94-101) on exact distances
     uint32_t best_i;
-    bool done;          // Q_SHADOW: first cube in array order whose exact test passes
-    uint32_t blocker;
+    bool done;          // Q_SHADOW: a passing cube was found ...
+    uint32_t blocker;   //           ... lowest list index so far (kNoHit: none)
     float tol;          // the ray's 2E (out)
     bool div_ok;        // the ray's RayPre::div_ok (out)
 };
 
-// One pass over the cube list for the whole wave.
+// One candidate cube (list index i, id cid, centre k, half size kh) against the wave's rays.  UNIFORM:
+// the same cube for every lane (wave-cooperative passes); otherwise each lane has its own (BVH walk).
 //   Q_NEAREST        approximate distances with error bound E for every cube the two-sided filter
 //                    proves to pass; cubes it can neither prove nor refute are evaluated exactly on the
 //                    spot (rare).  The caller decides the winner from (b1, b2, i1) and falls back to
 //                    Q_NEAREST_EXACT for lanes where b2 - b1 <= 2E ("contested": duplicates, ties).
-//   Q_NEAREST_EXACT  exact evaluation of every candidate for the lanes in `active`.
-//   Q_SHADOW         render.rs:44-70 list-order semantics, exclusion by id (render.rs:113).
+//   Q_NEAREST_EXACT  exact evaluation of every candidate for the lanes in `active`; the reference's
+//                    strict-< fold over the list (render.rs:94-101) = smallest distance, lowest index
+//                    among equals, which is how it is evaluated here in any visiting order.
+//   Q_SHADOW         render.rs:44-70: the passing cube with the lowest list index among those whose id
+//                    differs from the impact object's (render.rs:113); again in any visiting order.
+template <int MODE, bool UNIFORM>
+DEV void cube_candidate(const Params& P, const RayPre& q, bool active, bool any_zero, V3 o, V3 d, uint32_t impact_id, uint32_t i, uint32_t cid,
+                        float kx, float ky, float kz, float kh, QState& st PROF_ARG)
+{
+    float lo, hi;
+    cube_slab_approx(kx, ky, kz, kh, q, lo, hi);
+    const float gap = lo - hi;
+    bool live = active && !(gap > q.tol);  // not proven to miss
+    if constexpr (MODE == Q_SHADOW) live = live && (i < st.blocker) && (cid != impact_id);
+    bool sure = gap < -q.tol;  // proven to pass
+    if constexpr (MODE == Q_NEAREST) sure = sure && (__builtin_fabsf(lo) > q.err);  // and the sign of tmin is certain
+    if constexpr (MODE == Q_NEAREST_EXACT) sure = false;
+    if (any_zero) {
+        bool zmiss, zunsure;
+        zero_axis_check(q, o, kx, ky, kz, kh, zmiss, zunsure);
+        live = live && !zmiss;
+        sure = sure && !zunsure;
+    }
+    const bool amb = live && !sure;
+    float dist = (lo < 0.0f) ? hi : lo;  // cube.rs:145 on the approximate interval
+    PROF_COUNT(0, 1);
+    PROF_KCOUNT(ck, 1);
+    PROF_COUNT(1, wave_any(amb) ? 1 : 0);
+    PROF_COUNT(2, __builtin_popcountll(wave_ballot(amb && q.unsafe)));
+    PROF_COUNT(3, __builtin_popcountll(wave_ballot(amb && !q.unsafe && !(gap < -q.tol))));
+    PROF_COUNT(4, __builtin_popcountll(wave_ballot(amb && !q.unsafe && (gap < -q.tol))));
+    PROF_COUNT(5, __builtin_popcountll(wave_ballot(live)));
+    if (wave_any(amb)) {
+        if (amb) {
+            CubeRec c;
+            if constexpr (UNIFORM) c = load_cube_uniform(P.cubes, i);
+            else c = P.cubes[i];
+            float ed;
+            const bool pass = cube_exact(c, o, d, ed);
+            live = pass && (ed == ed);  // a NaN distance is Some but never wins (render.rs:95)
+            if constexpr (MODE == Q_SHADOW) live = pass;
+            dist = ed;
+        }
+    }
+    if constexpr (MODE == Q_NEAREST) {
+        const bool first = live && (dist < st.b1);
+        const float nb2 = first ? st.b1 : __builtin_fminf(st.b2, dist);
+        st.b2 = live ? nb2 : st.b2;
+        st.b1 = first ? dist : st.b1;
+        st.i1 = first ? i : st.i1;
+    } else if constexpr (MODE == Q_NEAREST_EXACT) {
+        const bool win = live && ((dist < st.best) || (dist == st.best && i < st.best_i));
+        st.best = win ? dist : st.best;
+        st.best_i = win ? i : st.best_i;
+    } else {
+        st.blocker = live ? i : st.blocker;  // live implies i < blocker
+        st.done = st.done || live;
+    }
+}
+
+// One pass over a short cube list (at most kSmallChunks chunks of 64, in list order) for the whole wave.
 template <int MODE>
-DEV void cube_query_group(const Params& P, const RayPre& q, const CullPre& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
+DEV void cube_query_small(const Params& P, const RayPre& q, const CullPre& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
     const uint32_t n = P.n_cubes;
     const bool any_zero = wave_any(active && q.zbits != 0u);
@@ -667,62 +729,15 @@ DEV void cube_query_group(const Params& P, const RayPre& q, const CullPre& cp, b
         while (M != 0ull) {
             const uint32_t b = (uint32_t)__builtin_ctzll(M);
             M &= M - 1ull;
-            const uint32_t i = base + b;
             const float kx = readlane_f(rec[0], b), ky = readlane_f(rec[1], b), kz = readlane_f(rec[2], b), kh = readlane_f(rec[3], b);
-            float lo, hi;
-            cube_slab_approx(kx, ky, kz, kh, q, lo, hi);
-            const float gap = lo - hi;
-            bool live = active && !(gap > q.tol);  // not proven to miss
+            uint32_t cid = 0u;
+            if constexpr (MODE == Q_SHADOW) cid = (uint32_t)__builtin_amdgcn_readlane((int)ids, (int)b);
+            cube_candidate<MODE, true>(P, q, active, any_zero, o, d, impact_id, base + b, cid, kx, ky, kz, kh, st PROF_PASS);
             if constexpr (MODE == Q_SHADOW) {
-                const uint32_t cid = (uint32_t)__builtin_amdgcn_readlane((int)ids, (int)b);
-                live = live && !st.done && (cid != impact_id);
-            }
-            bool sure = gap < -q.tol;  // proven to pass
-            if constexpr (MODE == Q_NEAREST) sure = sure && (__builtin_fabsf(lo) > q.err);  // and the sign of tmin is certain
-            if constexpr (MODE == Q_NEAREST_EXACT) sure = false;
-            if (any_zero) {
-                bool zmiss, zunsure;
-                zero_axis_check(q, o, kx, ky, kz, kh, zmiss, zunsure);
-                live = live && !zmiss;
-                sure = sure && !zunsure;
-            }
-            const bool amb = live && !sure;
-            float dist = (lo < 0.0f) ? hi : lo;  // cube.rs:145 on the approximate interval
-            PROF_COUNT(0, 1);
-            PROF_KCOUNT(ck, 1);
-            PROF_COUNT(1, wave_any(amb) ? 1 : 0);
-            PROF_COUNT(2, __builtin_popcountll(wave_ballot(amb && q.unsafe)));
-            PROF_COUNT(3, __builtin_popcountll(wave_ballot(amb && !q.unsafe && !(gap < -q.tol))));
-            PROF_COUNT(4, __builtin_popcountll(wave_ballot(amb && !q.unsafe && (gap < -q.tol))));
-            PROF_COUNT(5, __builtin_popcountll(wave_ballot(live)));
-            if (wave_any(amb)) {
-                if (amb) {
-                    const CubeRec c = load_cube_uniform(P.cubes, i);
-                    float ed;
-                    const bool pass = cube_exact(c, o, d, ed);
-                    live = pass && (ed == ed);  // a NaN distance is Some but never wins (render.rs:95)
-                    if constexpr (MODE == Q_SHADOW) live = pass;
-                    dist = ed;
-                }
-            }
-            if constexpr (MODE == Q_NEAREST) {
-                const bool first = live && (dist < st.b1);
-                const float nb2 = first ? st.b1 : __builtin_fminf(st.b2, dist);
-                st.b2 = live ? nb2 : st.b2;
-                st.b1 = first ? dist : st.b1;
-                st.i1 = first ? i : st.i1;
-            } else if constexpr (MODE == Q_NEAREST_EXACT) {
-                const bool win = live && (dist < st.best);  // strict <: lowest index wins ties
-                st.best = win ? dist : st.best;
-                st.best_i = win ? i : st.best_i;
-            } else {
-                if (wave_any(live)) {
-                    st.blocker = live ? i : st.blocker;
-                    st.done = st.done || live;
-                    if (!wave_any(active && !st.done)) {
-                        all_done = true;
-                        M = 0ull;
-                    }
+                // list order: the first passing cube is the answer; stop when every ray has one
+                if (!wave_any(active && !st.done)) {
+                    all_done = true;
+                    M = 0ull;
                 }
             }
         }
@@ -731,10 +746,124 @@ DEV void cube_query_group(const Params& P, const RayPre& q, const CullPre& cp, b
     }
 }
 
-// (An attempt to split a wave whose lanes carry two ray bundles - an 8x8 tile across a cube edge makes
-// every cube a candidate of the wave-level cull - into per-bundle passes cut the candidate count by a
-// fifth and was still 8 % slower overall: the extra cull set-ups and the register pressure cost more.)
+// lane-private chunk box (centre, three half extents): may some active ray of the wave meet it?
+DEV bool chunk_test(f32x4 k, f32x4 h, const CullPre& c)
+{
+    const float akx = __builtin_fabsf(k[0]), aky = __builtin_fabsf(k[1]), akz = __builtin_fabsf(k[2]);
+    const float gxy = __builtin_fmaf(k[0], c.dyc, __builtin_fmaf(-k[1], c.dxc, -c.wxyc));
+    const float lxy = __builtin_fmaf(h[0], c.ay, __builtin_fmaf(h[1], c.ax, __builtin_fmaf(akx + aky, c.dr, c.wr)));
+    const float gyz = __builtin_fmaf(k[1], c.dzc, __builtin_fmaf(-k[2], c.dyc, -c.wyzc));
+    const float lyz = __builtin_fmaf(h[1], c.az, __builtin_fmaf(h[2], c.ay, __builtin_fmaf(aky + akz, c.dr, c.wr)));
+    const float gzx = __builtin_fmaf(k[2], c.dxc, __builtin_fmaf(-k[0], c.dzc, -c.wzxc));
+    const float lzx = __builtin_fmaf(h[2], c.ax, __builtin_fmaf(h[0], c.az, __builtin_fmaf(akz + akx, c.dr, c.wr)));
+    const bool sep = (__builtin_fabsf(gxy) > lxy) || (__builtin_fabsf(gyz) > lyz) || (__builtin_fabsf(gzx) > lzx);
+    return c.all || !sep;
+}
+
+// One pass over a long cube list.  The cull stream of such a scene is in Morton order of the cube centres
+// (rt_scene_upload), so a chunk of 64 consecutive records is spatially compact and has a tight bounding
+// box: lane j first tests chunk j's box against the wave's rays (same separating-axis test, three half
+// extents), and only chunks that pass are loaded and culled cube by cube.  Candidates therefore arrive in
+// stream order, not list order; cube_perm gives each its list index, and cube_candidate's folds do not
+// depend on the visiting order.  (The reference walks all N cubes per ray; 10k cubes = 157 chunks, of
+// which a coherent bundle meets a handful.)
 template <int MODE>
+DEV void cube_query_large(const Params& P, const RayPre& q, const CullPre& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
+{
+    const uint32_t n = P.n_cubes, n_chunks = P.n_chunks;
+    const bool any_zero = wave_any(active && q.zbits != 0u);
+    PROF_COUNT(6, 1);
+    PROF_KCOUNT(qk, 1);
+    PROF_MARK(PH_PRE);
+    const uint32_t lane = threadIdx.x & 63u;
+    const f32x4* filt = (const f32x4*)P.cube_filt;
+    const f32x4* boxes = (const f32x4*)P.chunk_box;
+    for (uint32_t cg = 0; cg < n_chunks; cg += 64u) {
+        const f32x4 bk = boxes[(size_t)(cg + lane) * 2u], bh = boxes[(size_t)(cg + lane) * 2u + 1u];  // padded to a multiple of 64 chunks
+        unsigned long long CM = wave_ballot(chunk_test(bk, bh, cp) && (cg + lane < n_chunks));
+        while (CM != 0ull) {
+            const uint32_t c = (uint32_t)__builtin_ctzll(CM);
+            CM &= CM - 1ull;
+            const uint32_t base = (cg + c) * 64u;
+            const f32x4 rec = filt[base + lane];
+            const uint32_t perm = P.cube_perm[base + lane];
+            uint32_t ids = 0u;
+            if constexpr (MODE == Q_SHADOW) ids = P.cube_id[base + lane];
+            unsigned long long M = wave_ballot(cull_test(rec, cp) && (base + lane < n));
+            PROF_MARK(PH_CULL);
+            while (M != 0ull) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(M);
+                M &= M - 1ull;
+                const float kx = readlane_f(rec[0], b), ky = readlane_f(rec[1], b), kz = readlane_f(rec[2], b), kh = readlane_f(rec[3], b);
+                const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)perm, (int)b);
+                uint32_t cid = 0u;
+                if constexpr (MODE == Q_SHADOW) cid = (uint32_t)__builtin_amdgcn_readlane((int)ids, (int)b);
+                cube_candidate<MODE, true>(P, q, active, any_zero, o, d, impact_id, i, cid, kx, ky, kz, kh, st PROF_PASS);
+            }
+            PROF_MARK(PH_CAND);
+        }
+    }
+}
+
+// One pass for an INCOHERENT bundle (an 8x8 tile across cube edges after a bounce: lanes going every
+// way).  The wave-level cull keeps nearly every cube for such a wave (measured: all 97 cubes of the
+// diorama, thousands of the 10k-cube world, and these waves are the frame's critical path), so each
+// lane walks the BVH with its own line instead: stackless depth-first order, the separating-axis test
+// of cull_test with the lane's own direction and moment (no radii), the same rounding slack.  Leaf
+// cubes go through cube_candidate per lane.  (Splitting the wave into a few coherent sub-bundles was
+// tried first: a fifth fewer candidates, 8 % slower.)
+template <int MODE>
+DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
+{
+    const bool any_zero = wave_any(active && q.zbits != 0u);
+    PROF_COUNT(6, 1);
+    PROF_KCOUNT(qk, 1);
+    PROF_MARK(PH_PRE);
+    const float wxy = o.x * d.y - o.y * d.x, wyz = o.y * d.z - o.z * d.y, wzx = o.z * d.x - o.x * d.z;
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    const float om = __builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fmaxf(__builtin_fabsf(o.y), __builtin_fabsf(o.z)));
+    const float slack = 0x1p-17f * (P.bound_max + om + 1.0f) * __builtin_fmaxf(ax + ay + az, 1.0f);  // as in cull_pre
+    const uint32_t end = P.n_bvh_nodes;
+    const f32x4* nodes = (const f32x4*)P.bvh;
+    const f32x4* filt = (const f32x4*)P.cube_filt;
+    uint32_t node = active ? 0u : end;
+    while (wave_any(node != end)) {
+        const bool on = node != end;
+        const uint32_t ni = on ? node : 0u;
+        const f32x4 a = nodes[(size_t)ni * 2u], b = nodes[(size_t)ni * 2u + 1u];
+        const float a3 = a[3], b3 = b[3];  // scalar copies first: see the note at u2f
+        const uint32_t first_count = __builtin_bit_cast(uint32_t, a3), skip = __builtin_bit_cast(uint32_t, b3);
+        const float gxy = __builtin_fmaf(a[0], d.y, __builtin_fmaf(-a[1], d.x, -wxy));
+        const float lxy = __builtin_fmaf(b[0], ay, __builtin_fmaf(b[1], ax, slack));
+        const float gyz = __builtin_fmaf(a[1], d.z, __builtin_fmaf(-a[2], d.y, -wyz));
+        const float lyz = __builtin_fmaf(b[1], az, __builtin_fmaf(b[2], ay, slack));
+        const float gzx = __builtin_fmaf(a[2], d.x, __builtin_fmaf(-a[0], d.z, -wzx));
+        const float lzx = __builtin_fmaf(b[2], ax, __builtin_fmaf(b[0], az, slack));
+        const bool sep = (__builtin_fabsf(gxy) > lxy) || (__builtin_fabsf(gyz) > lyz) || (__builtin_fabsf(gzx) > lzx);
+        const bool meet = on && (q.wild || !sep);  // NaN compares false -> meet
+        const uint32_t cnt = first_count & 7u, first = first_count >> 3;
+        const bool leaf = meet && (cnt != 0u);
+        PROF_MARK(PH_CULL);
+        if (wave_any(leaf)) {
+            for (uint32_t c = 0; c < 4u; ++c) {
+                const bool lc = leaf && (c < cnt);
+                if (!wave_any(lc)) break;
+                const uint32_t sp = P.bvh_items[lc ? first + c : 0u];  // stream record of the leaf's c-th cube
+                const f32x4 rec = filt[sp];
+                const uint32_t i = P.cube_perm[sp];
+                uint32_t cid = 0u;
+                if constexpr (MODE == Q_SHADOW) cid = P.cube_id[sp];
+                cube_candidate<MODE, false>(P, q, lc, any_zero, o, d, impact_id, i, cid, rec[0], rec[1], rec[2], rec[3], st PROF_PASS);
+            }
+            PROF_MARK(PH_CAND);
+        }
+        node = on ? ((meet && cnt == 0u) ? node + 1u : skip) : end;  // indices only grow: the walk ends
+    }
+}
+
+// LARGE (a kernel template parameter chosen by the length of the cube list) keeps the long-list code out
+// of the kernel that renders short lists: compiled in, it cost the 97-cube benchmark scene 6 %.
+template <int MODE, bool LARGE>
 DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
     if (P.n_cubes == 0u) return;
@@ -742,12 +871,19 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
     st.tol = q.tol;
     st.div_ok = q.div_ok;
     const CullPre cp = cull_pre(P, active, o, d, q.wild);
-    cube_query_group<MODE>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+    if constexpr (LARGE) {
+        // how much the wave's spread inflates every cube in cull_test, against the cubes' own size (wave-uniform)
+        const bool coherent = cp.all || !(__builtin_fmaf(2.0f * P.bound_max, cp.dr, cp.wr_raw) > P.coherent_thr);
+        if (coherent) cube_query_large<MODE>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+        else cube_query_bvh<MODE>(P, q, active, o, d, impact_id, st PROF_PASS);
+    } else {
+        cube_query_small<MODE>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+    }
 }
 
 // ---------------------------------------------------------------- nearest hit (render.rs:87-101)
 // `pass` is wave-uniform: PASS_SPHERES walks the sphere list, PASS_CUBES the cube list.
-template <bool COUNT>
+template <bool COUNT, bool LARGE>
 DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3 d, bool& div_ok, Counters& cnt PROF_ARG)
 {
     uint32_t best_idx = kNoHit;
@@ -756,13 +892,13 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
         QState st;
         st.b1 = __builtin_inff(); st.b2 = __builtin_inff(); st.i1 = kNoHit;
         st.best = __builtin_inff(); st.best_i = kNoHit; st.done = false; st.blocker = kNoHit; st.tol = 0.0f; st.div_ok = false;
-        cube_query<Q_NEAREST>(P, active, o, d, 0u, st PROF_PASS);
+        cube_query<Q_NEAREST, LARGE>(P, active, o, d, 0u, st PROF_PASS);
         best_idx = active ? st.i1 : kNoHit;
         div_ok = st.div_ok;
         // contested: a second candidate within 2E of the best (exact duplicates, shared edges).  NaN -> contested.
         const bool contested = active && (st.i1 != kNoHit) && !(st.b2 - st.b1 > st.tol);
         if (wave_any(contested)) {
-            cube_query<Q_NEAREST_EXACT>(P, contested, o, d, 0u, st PROF_PASS);
+            cube_query<Q_NEAREST_EXACT, LARGE>(P, contested, o, d, 0u, st PROF_PASS);
             PROF_MARK(PH_CONTESTED);
             best_idx = contested ? st.best_i : best_idx;
         }
@@ -786,7 +922,7 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
 // ---------------------------------------------------------------- shadow (render.rs:44-70)
 // First object in array order, among those whose id differs from the impact object's
 // (render.rs:113), whose ray_intersect returns Some.  Not the nearest one.
-template <bool COUNT>
+template <bool COUNT, bool LARGE>
 DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V3 light_pos, uint32_t impact_id, uint32_t& blocker, Counters& cnt PROF_ARG)
 {
     const V3 dir = vnormalize(vsub(light_pos, origin));
@@ -797,7 +933,7 @@ DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V
         QState st;
         st.b1 = 0.0f; st.b2 = 0.0f; st.i1 = kNoHit; st.best = 0.0f; st.best_i = kNoHit;
         st.done = false; st.blocker = kNoHit; st.tol = 0.0f; st.div_ok = false;
-        cube_query<Q_SHADOW>(P, active, origin, dir, impact_id, st PROF_PASS);
+        cube_query<Q_SHADOW, LARGE>(P, active, origin, dir, impact_id, st PROF_PASS);
         blocker = (active && st.done) ? st.blocker : kNoHit;
         if (wave_any(blocker != kNoHit)) {
             // the blocker's exact distance (per-lane gather; the loop only proved that it passes)
@@ -880,7 +1016,7 @@ DEV uint32_t node_finish(const Params& P, uint32_t sumf, float k_r, float k_t, u
 
 // One pass of render.rs:298-312 (spheres with ambient 1, or cubes with ambient_light) for the wave's
 // 64 primary rays: returns the packed colour, the primary hit index and the tree hash per lane.
-template <bool DBG, bool COUNT>
+template <bool DBG, bool COUNT, bool LARGE>
 DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d, float ambient, uint32_t* stk, uint32_t& hash, uint32_t& hit_idx,
                         Totals& tot PROF_ARG)
 {
@@ -901,7 +1037,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
             PROF_MARK(PH_OTHER);
             PROF_KIND(depth * 2u);
             bool div_ok;
-            const uint32_t idx = nearest_query<COUNT>(P, pass, act, o, d, div_ok, cnt PROF_PASS);
+            const uint32_t idx = nearest_query<COUNT, LARGE>(P, pass, act, o, d, div_ok, cnt PROF_PASS);
             if (depth == 0u) hit_idx = idx;
             uint32_t h = hmix(kHashBasis, idx);
             const bool hit_any = act && (idx != kNoHit);
@@ -934,7 +1070,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     uint32_t blocker;
                     PROF_MARK(PH_SHADE);
                     PROF_KIND(depth * 2u + 1u);
-                    const float shadow = shadow_query<COUNT>(P, pass, hit_any, hit.p, lp, hit.id, blocker, cnt PROF_PASS);
+                    const float shadow = shadow_query<COUNT, LARGE>(P, pass, hit_any, hit.p, lp, hit.id, blocker, cnt PROF_PASS);
                     if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
                     const float light_intensity = L.intensity * (1.0f - shadow);
                     const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
@@ -1106,7 +1242,7 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
 #ifndef RTX_WAVES_PER_EU
 #define RTX_WAVES_PER_EU 4
 #endif
-template <bool DBG, bool COUNT>
+template <bool DBG, bool COUNT, bool LARGE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PER_EU, RTX_WAVES_PER_EU))) void render_kernel(const Params P)
 {
     __shared__ uint32_t stk[kStackDepth * frame_words<DBG>() * 64];
@@ -1205,7 +1341,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
                     cnt.v[2] += tests; cnt.v[7] += tests;
                 }
             } else {
-                c = trace_tree<DBG, COUNT>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
+                c = trace_tree<DBG, COUNT, LARGE>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
             }
             if (pass == PASS_SPHERES) { px = c; hs = hh; hit_s = hi; }
             else { px = (px == P.sky) ? c : px; hc = hh; hit_c = hi; }
@@ -1386,10 +1522,20 @@ int launch_render(const Params& p, int variant, void* stream)
     // only known on the device, so the grid covers both extremes and the surplus exits at once
     dim3 grid(tiles + (tiles + kPaintGroup - 1u) / kPaintGroup, 1u, 1u), block(64u, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
+    const bool large = p.n_chunks > 0u;  // long cube list: Morton-ordered stream, chunk boxes, BVH
     switch (variant) {
-    case kVariantDebug: hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, s, p); break;
-    case kVariantCount: hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, s, p); break;
+    case kVariantDebug:
+        if (large) hipLaunchKernelGGL((render_kernel<true, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((render_kernel<true, false, false>), grid, block, 0, s, p);
+        break;
+    case kVariantCount:
+        if (large) hipLaunchKernelGGL((render_kernel<false, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, 0, s, p);
+        break;
+    default:
+        if (large) hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, 0, s, p);
+        break;
     }
     return (int)hipGetLastError();
 }

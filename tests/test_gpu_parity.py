@@ -223,3 +223,15 @@ def test_shared_reciprocal_division_is_ieee(gpu_ctx):
     for seed in (1, 2):
         bad, n = gpu_ctx.selftest_division(1 << 31, seed=seed)
         assert n > (1 << 30) and bad == 0, (bad, n)
+
+
+@pytest.mark.parametrize("scale", ["0", "1e9"])
+def test_long_list_paths_forced(gpu_ctx, oracle_mod, scale, monkeypatch):
+    """Long cube lists have two traversals (wave-cooperative over Morton-ordered chunks with chunk boxes,
+    per-lane BVH walk for incoherent bundles); the choice per wave is a threshold.  Force each one for
+    every wave (RTX950_COHERENT_SCALE is read by rt_scene_upload) and require the same parity."""
+    monkeypatch.setenv("RTX950_COHERENT_SCALE", scale)
+    scene = rt.synthetic_scene(n_cubes=900, n_spheres=8)
+    f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, scene, 200, 120)
+    assert_parity(gfb, gpl, ofb, opl, f"synthetic 900c, coherent scale {scale}")
+    assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()

@@ -18,7 +18,7 @@ traffic_out = workload = None
 if args and args[0] == "--traffic":
     traffic_out, workload = args[1], args[2]
     args = args[3:]
-needle = args[0] if args else "render_kernel<false, false>"
+needle = args[0] if args else "render_kernel<false, false"
 def newest(pattern):
     """one file per directory: the most recent (gpurun merges new results into old local directories)"""
     best = {}
