@@ -33,6 +33,7 @@ struct rt_ctx {
     uint32_t* d_cube_id = nullptr;
     uint32_t* d_cube_perm = nullptr;
     BvhNode* d_bvh = nullptr;
+    float* d_sphere_filt = nullptr;
     uint32_t* d_bvh_items = nullptr;
     float* d_chunk_box = nullptr;
     uint32_t* d_cube_mat = nullptr;
@@ -118,6 +119,8 @@ void free_scene(rt_ctx* c)
     c->d_cube_perm = nullptr;
     (void)hipFree(c->d_bvh);
     c->d_bvh = nullptr;
+    (void)hipFree(c->d_sphere_filt);
+    c->d_sphere_filt = nullptr;
     (void)hipFree(c->d_bvh_items);
     c->d_bvh_items = nullptr;
     (void)hipFree(c->d_chunk_box);
@@ -541,7 +544,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
             if (hi_i - lo_i <= 4) {
                 nodes[me].first_count = (uint32_t)((lo_i << 3) | (hi_i - lo_i));
             } else {
-                nodes[me].first_count = 0u;
+                uint32_t min_idx = 0xFFFFFFFFu;  // lowest list index below this node (shadow pruning)
+                for (size_t j = lo_i; j < hi_i; ++j) min_idx = std::min(min_idx, perm[items[j]]);
+                nodes[me].first_count = min_idx << 3;  // count bits 0: inner node
                 const size_t mid = (lo_i + hi_i) / 2;
                 build(lo_i, mid);
                 build(mid, hi_i);
@@ -558,10 +563,24 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     }
     std::vector<SphereRec> hs(n_spheres);
     std::vector<SphereMeta> hsm(n_spheres);
+    const size_t n_sfilt = ((n_spheres + 63) / 64) * 64 + 64;
+    std::vector<float> hsf(n_sfilt * 4);
+    for (size_t i = 0; i < n_sfilt; ++i) {
+        hsf[4 * i + 0] = 1e18f; hsf[4 * i + 1] = -1e18f; hsf[4 * i + 2] = 1e18f; hsf[4 * i + 3] = 1.0f;
+    }
+    float sbmax = 0.0f;
+    bool sphere_ok = true;
     for (size_t i = 0; i < n_spheres; ++i) {
         hs[i] = SphereRec{spheres[i].center.x, spheres[i].center.y, spheres[i].center.z, spheres[i].radius};
         hsm[i] = SphereMeta{spheres[i].id, spheres[i].material};
+        const float v[4] = {spheres[i].center.x, spheres[i].center.y, spheres[i].center.z, std::fabs(spheres[i].radius)};
+        for (int k = 0; k < 4; ++k) {
+            hsf[4 * i + k] = v[k];
+            if (!(std::fabs(v[k]) <= 0x1p20f)) sphere_ok = false;  // also NaN
+        }
+        for (int k = 0; k < 3; ++k) sbmax = std::max(sbmax, std::fabs(v[k]) + v[3]);
     }
+    if (!std::isfinite(sbmax)) { sbmax = 0.0f; sphere_ok = false; }
     std::vector<MatRec> hm(n_materials);
     for (size_t i = 0; i < n_materials; ++i) {
         hm[i] = MatRec{materials[i].specular, materials[i].albedo0, materials[i].albedo1, materials[i].reflectivity,
@@ -584,6 +603,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     if ((rc = upload(ctx, &ctx->d_bvh_items, items)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_spheres, hs)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_sphere_meta, hsm)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_sphere_filt, hsf)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_mats, hm)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_atlas, ha)) != RT_OK) return rc;
 
@@ -603,6 +623,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     if (const char* e = getenv("RTX950_COHERENT_SCALE")) b.coherent_thr *= (float)atof(e);  // tuning experiments
     b.spheres = ctx->d_spheres;
     b.sphere_meta = ctx->d_sphere_meta;
+    b.sphere_filt = ctx->d_sphere_filt;
+    b.sphere_bound_max = sbmax;
+    b.sphere_ok = sphere_ok ? 1u : 0u;
     b.mats = ctx->d_mats;
     b.atlas = ctx->d_atlas;
     b.n_cubes = (uint32_t)n_cubes;

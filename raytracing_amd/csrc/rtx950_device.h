@@ -31,7 +31,7 @@ static_assert(sizeof(CubeRec) == 32, "CubeRec must be one dwordx8");
 // stack: after a node, go to node + 1 (its first child) if the line meets the box, else to `skip`.
 struct BvhNode {
     float cx, cy, cz;      // box centre
-    uint32_t first_count;  // leaf: (first item << 3) | count (1..4); inner node: 0
+    uint32_t first_count;  // leaf: (first item << 3) | count (1..4); inner node: lowest list index below it << 3
     float hx, hy, hz;      // half extents (rounded up)
     uint32_t skip;         // next node when this subtree is done or missed; n_bvh_nodes = end
 };
@@ -83,6 +83,9 @@ struct Params {
     float coherent_thr;  // a wave whose cull inflation (2 B dr + wr) exceeds this walks the BVH per lane
     const SphereRec* spheres;
     const SphereMeta* sphere_meta;
+    const float* sphere_filt;   // ceil64(n_spheres) x (centre.xyz, |radius|): the spheres' cull stream
+    float sphere_bound_max;     // max |centre coordinate| + |radius|
+    uint32_t sphere_ok;         // 1 if every sphere is finite and within 2^20
     const MatRec* mats;
     const uint32_t* atlas;
     uint32_t n_cubes, n_spheres;

@@ -578,10 +578,11 @@ struct CullPre {  // wave-uniform
     float wr_raw;               // ... without the slack
     float sxy, syz, szx;        // upper bounds of |d_i| + |d_j|
     float ax, ay, az;           // upper bounds of |d_i|
+    float omax;                 // largest origin coordinate magnitude
     bool all;                   // some active ray is non-finite or huge: keep every cube
 };
 
-DEV CullPre cull_pre(const Params& P, bool active, V3 o, V3 d, bool wild)
+DEV CullPre cull_pre(bool active, V3 o, V3 d, bool wild, float bound_max)
 {
     CullPre c;
     const unsigned long long am = wave_ballot(active);
@@ -605,8 +606,9 @@ DEV CullPre cull_pre(const Params& P, bool active, V3 o, V3 d, bool wild)
     //   this test's own fma chains and the per-lane moments      <= ~12 u (B + O) D
     //   the reference's rounded t values vs exact arithmetic      <= ~12 u (B + O) D   (see cube_slab_approx)
     // 2^-17 (B + O + 1) max(D, 1) = 128 u (...) covers both several times over.
-    const float slack = 0x1p-17f * (P.bound_max + omax + 1.0f) * __builtin_fmaxf(ax + ay + az, 1.0f);
+    const float slack = 0x1p-17f * (bound_max + omax + 1.0f) * __builtin_fmaxf(ax + ay + az, 1.0f);
     c.wr = wrm + slack;
+    c.omax = omax;
     c.wr_raw = wrm;
     return c;
 }
@@ -840,8 +842,25 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
         const float gzx = __builtin_fmaf(a[2], d.x, __builtin_fmaf(-a[0], d.z, -wzx));
         const float lzx = __builtin_fmaf(b[2], ax, __builtin_fmaf(b[0], az, slack));
         const bool sep = (__builtin_fabsf(gxy) > lxy) || (__builtin_fabsf(gyz) > lyz) || (__builtin_fabsf(gzx) > lzx);
-        const bool meet = on && (q.wild || !sep);  // NaN compares false -> meet
+        bool meet = on && (q.wild || !sep);  // NaN compares false -> meet
         const uint32_t cnt = first_count & 7u, first = first_count >> 3;
+        // Prune subtrees that cannot change the lane's result.  Every cube in the box has distance
+        // (cube.rs:145: tmin, or tmax if tmin < 0) >= the box's own entry parameter lo, negative ones
+        // included; lo comes from the slab filter with the box's half extents (same error bound E =
+        // tol/2, the box lies within the scene bounds).  A cube with approximate distance above
+        // b1 + tol is neither the winner nor "contested", one with exact distance above `best` cannot
+        // win or tie.  Unsafe rays have tol = inf and NaN compares false: no pruning.  Shadow: only
+        // the lowest list index matters, and an inner node carries the lowest index below it.
+        if constexpr (MODE == Q_SHADOW) {
+            meet = meet && !(cnt == 0u && first >= st.blocker);
+        } else {
+            const float nx = __builtin_fmaf(b[0], q.na_xy[0], __builtin_fmaf(a[0], q.r_xy[0], q.c_xy[0]));
+            const float ny = __builtin_fmaf(b[1], q.na_xy[1], __builtin_fmaf(a[1], q.r_xy[1], q.c_xy[1]));
+            const float nz = __builtin_fmaf(b[2], q.a_z_pm[0], __builtin_fmaf(a[2], q.rc_z[0], q.rc_z[1]));
+            const float lo = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+            if constexpr (MODE == Q_NEAREST) meet = meet && !(lo > st.b1 + 2.0f * q.tol);
+            else meet = meet && !(lo - q.tol > st.best);
+        }
         const bool leaf = meet && (cnt != 0u);
         PROF_MARK(PH_CULL);
         if (wave_any(leaf)) {
@@ -870,7 +889,7 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
     const RayPre q = ray_pre(P, o, d);
     st.tol = q.tol;
     st.div_ok = q.div_ok;
-    const CullPre cp = cull_pre(P, active, o, d, q.wild);
+    const CullPre cp = cull_pre(active, o, d, q.wild, P.bound_max);
     if constexpr (LARGE) {
         // how much the wave's spread inflates every cube in cull_test, against the cubes' own size (wave-uniform)
         const bool coherent = cp.all || !(__builtin_fmaf(2.0f * P.bound_max, cp.dr, cp.wr_raw) > P.coherent_thr);
@@ -878,6 +897,60 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
         else cube_query_bvh<MODE>(P, q, active, o, d, impact_id, st PROF_PASS);
     } else {
         cube_query_small<MODE>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+    }
+}
+
+// ---------------------------------------------------------------- sphere queries
+// The same wave-level cull with the sphere's bounding box (centre, half = radius), then the reference's
+// test (sphere_exact) for the candidates, in list order.  One difference from the cubes: the reference's
+// discriminant b^2 - 4ac is computed in f32 with cancellation and can come out positive for a line that
+// misses the sphere.  With u = 2^-24, |error| <= (60 |oc|^2 + 24 r^2) u |d|^2, so a miss by more than
+// 7.5 u |oc|^2 / r + 3 u r cannot be reported as a hit; |oc|^2 <= 3 (O + B)^2 with O, B the largest origin
+// and sphere coordinate.  The box is therefore inflated by 2^-17 (O + B + 1)^2 / r (6x that bound; r -> 0
+// gives an infinite box: always a candidate).
+DEV bool ray_wild(V3 o, V3 d)
+{
+    const float bigd = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    const float bigo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+    const bool finite = (d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (o.x == o.x) && (o.y == o.y) && (o.z == o.z);
+    return !(finite && bigd <= 0x1p40f && bigo <= 0x1p20f);
+}
+
+// NEAREST: render.rs:87-101 over the sphere list (strict <, list order).  SHADOW: render.rs:44-70, the
+// first sphere in list order whose id differs from the impact object's and that is hit.
+template <bool SHADOW>
+DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, uint32_t& best_idx, float& best_dist)
+{
+    const uint32_t n = P.n_spheres;
+    if (n == 0u) return;
+    const CullPre cp = cull_pre(active, o, d, ray_wild(o, d) || (P.sphere_ok == 0u), P.sphere_bound_max);
+    const float grow = 0x1p-17f * (cp.omax + P.sphere_bound_max + 1.0f) * (cp.omax + P.sphere_bound_max + 1.0f);
+    const uint32_t lane = threadIdx.x & 63u;
+    const f32x4* filt = (const f32x4*)P.sphere_filt;
+    bool done = false;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        f32x4 rec = filt[base + lane];  // (centre, |radius|), padded to a multiple of 64
+        rec[3] = __builtin_fmaf(grow, __builtin_amdgcn_rcpf(rec[3]), rec[3]);
+        unsigned long long M = wave_ballot(cull_test(rec, cp) && (base + lane < n));
+        while (M != 0ull) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(M);
+            M &= M - 1ull;
+            const uint32_t i = base + b;
+            const SphereRec s = load_sphere_uniform(P.spheres, i);
+            float dist = 0.0f;
+            const bool hit = sphere_exact(s, o, d, dist);
+            if constexpr (SHADOW) {
+                const bool pass = hit && active && !done && (load_sphere_meta_uniform(P.sphere_meta, i).id != impact_id);
+                best_idx = pass ? i : best_idx;
+                best_dist = pass ? dist : best_dist;
+                done = done || pass;
+                if (!wave_any(active && !done)) return;
+            } else {
+                const bool win = hit && active && (dist < best_dist);
+                best_dist = win ? dist : best_dist;
+                best_idx = win ? i : best_idx;
+            }
+        }
     }
 }
 
@@ -904,16 +977,9 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
         }
         if constexpr (COUNT) cnt.cube_tests += active ? P.n_cubes : 0u;
     } else {
-        const uint32_t n = P.n_spheres;
         float best_dist = __builtin_inff();
-        for (uint32_t i = 0; i < n; ++i) {
-            const SphereRec s = load_sphere_uniform(P.spheres, i);
-            float dist = 0.0f;
-            const bool win = sphere_exact(s, o, d, dist) && active && (dist < best_dist);
-            best_dist = win ? dist : best_dist;
-            best_idx = win ? i : best_idx;
-        }
-        if constexpr (COUNT) cnt.sphere_tests += active ? n : 0u;
+        sphere_query<false>(P, active, o, d, 0u, best_idx, best_dist);
+        if constexpr (COUNT) cnt.sphere_tests += active ? P.n_spheres : 0u;
     }
     if constexpr (COUNT) cnt.nearest_rays += active ? 1u : 0u;
     return best_idx;
@@ -950,18 +1016,15 @@ DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V
             }
         }
     } else {
-        const uint32_t n = P.n_spheres;
-        bool done = false;
-        for (uint32_t i = 0; i < n; ++i) {
-            const SphereRec s = load_sphere_uniform(P.spheres, i);
-            const bool tested = active && !done && (load_sphere_meta_uniform(P.sphere_meta, i).id != impact_id);
-            if constexpr (COUNT) cnt.sphere_tests += tested ? 1u : 0u;
-            float dist = 0.0f;
-            const bool pass_i = sphere_exact(s, origin, dir, dist) && tested;
-            blocker = pass_i ? i : blocker;
-            sdist = pass_i ? dist : sdist;
-            done = done || pass_i;
-            if (!wave_any(active && !done)) break;
+        sphere_query<true>(P, active, origin, dir, impact_id, blocker, sdist);
+        if constexpr (COUNT) {
+            // executed tests = spheres up to and including the blocker whose id differs from the impact id
+            const uint32_t n = P.n_spheres;
+            const uint32_t limit = (blocker != kNoHit) ? blocker + 1u : n;
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t id = load_sphere_meta_uniform(P.sphere_meta, i).id;
+                cnt.sphere_tests += (active && i < limit && id != impact_id) ? 1u : 0u;
+            }
         }
     }
     float shadow = 0.0f;
