@@ -104,13 +104,15 @@ struct Params {
     const uint32_t* tile_stamps;
     uint32_t tiles_x, tiles_y;
     uint32_t frame_id;
-    // Work queue of this launch (build_queue -> render_kernel): words 0..8 = number of listed tiles per
-    // class (zeroed per frame by classify_tiles; classes 0..7 = traced tiles by cost, class 8 = tiles that
-    // are only painted), class c's entries start at word kQueueBase + c * grid_tx * grid_ty; an entry is tile column | tile row << 16 in the launch's own grid of grid_tx x
+    // Work queue of this launch (build_queue -> render_kernel): two header banks of 16
+    // words, bank qsel holds the number of listed tiles per class (classes 0..7 = traced tiles by cost,
+    // class 8 = tiles that are only painted); class c's entries start at word kQueueBase + c * grid_tx *
+    // grid_ty; an entry is tile column | no-cubes flag << 15 | tile row << 16 in the launch's own grid of grid_tx x
     // grid_ty 8x8 tiles.  tile_cost[row * grid_tx + column] = cycles the tile took in the previous launch
     // on this context (0: unknown); it only orders the queue, heaviest class first.
     uint32_t* queue;
     uint32_t* tile_cost;
+    uint32_t qsel;  // header bank of this launch (0/1): counts at words qsel * 16 + class; the other bank is zeroed for the next launch
     uint32_t grid_tx, grid_ty;
     float ambient;
     uint32_t sky;
@@ -138,7 +140,8 @@ struct TileParams {
     uint32_t width, height, tiles_x, tiles_y;
     uint32_t* stamps;
     uint32_t frame_id;
-    uint32_t* queue;  // header words 0..15 are zeroed by block 0
+    uint32_t* queue;  // block 0 zeroes header bank qsel ^ 1 (the next launch's)
+    uint32_t qsel;
 };
 constexpr uint32_t kStampBase = 64;  // first per-tile word
 constexpr uint32_t kQueueBase = 64;  // first tile entry of Params::queue

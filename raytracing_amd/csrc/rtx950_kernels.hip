@@ -1057,6 +1057,7 @@ DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V
 //    instruction cache - and several hundred spilled registers.)
 // Frame of a node waiting for its children, per lane:
 enum { F_RO = 0, F_RD = 3, F_SUMF = 6, F_C0 = 7, F_KR = 8, F_KT = 9, F_H = 10, F_H0 = 11 };
+constexpr uint32_t kEntryNoCubes = 1u << 15;  // queue entry flag: the tile's cube pass is answered without tracing
 constexpr uint32_t kPaintGroup = 16;  // untraced tiles painted per surplus workgroup
 constexpr int kStackDepth = 3;  // nodes at depth 0..2 can wait for traced children (max_depth <= 3)
 template <bool DBG>
@@ -1276,7 +1277,8 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
     const uint32_t bx = valid ? t % P.grid_tx : 0u, by = valid ? t / P.grid_tx : 0u;
     const uint32_t ty0 = tile_y0(P, by);
     const bool in_band = valid && (ty0 < P.y1);
-    const bool traced = in_band && ((P.n_spheres != 0u) || !tile_has_no_cubes(P, bx, ty0));
+    const bool no_cubes = tile_has_no_cubes(P, bx, ty0);
+    const bool traced = in_band && ((P.n_spheres != 0u) || !no_cubes);
     // cost class from the tile's cycle count in the previous launch: < 8K cycles -> 0, then one class per
     // doubling, >= 512K -> 7
     const uint32_t cost = valid ? P.tile_cost[t] : 0u;
@@ -1290,9 +1292,9 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
     uint32_t rank = 0u;
     if (in_band) rank = atomicAdd(&n_cls[cls], 1u);
     __syncthreads();
-    if (threadIdx.x <= kCostClasses) base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[threadIdx.x], n_cls[threadIdx.x]) : 0u;
+    if (threadIdx.x <= kCostClasses) base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[P.qsel * 16u + threadIdx.x], n_cls[threadIdx.x]) : 0u;
     __syncthreads();
-    if (in_band) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (by << 16);
+    if (in_band) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (no_cubes ? kEntryNoCubes : 0u) | (by << 16);
 }
 
 // render_kernel: single-wave workgroups, one lane per pixel of an 8x8 tile (coherent rays give tight
@@ -1322,7 +1324,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
         KCONST uint32_t* q = (KCONST uint32_t*)P.queue;
         bool found = false;
         for (uint32_t k = kCostClasses; k-- > 0u;) {
-            const uint32_t n_k = q[k];
+            const uint32_t n_k = q[P.qsel * 16u + k];
             if (!found && idx < n_k) {
                 entry = q[kQueueBase + k * tiles + idx];
                 found = true;
@@ -1333,12 +1335,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
             // The traced tiles are all handed out: this workgroup paints kPaintGroup of the others (sky
             // colour, "no hit" planes) and counts the rays the reference would still have cast for them.
             KCONST uint32_t* sky_list = q + kQueueBase + kCostClasses * tiles;
-            const uint32_t n_sky = q[kCostClasses];
+            const uint32_t n_sky = q[P.qsel * 16u + kCostClasses];
             const uint32_t no_hash = hmix(kHashBasis, kNoHit);
             const uint32_t px_hash = hmix(hmix(kHashBasis, no_hash), no_hash);
             for (uint32_t j = idx * kPaintGroup; j < n_sky && j < (idx + 1u) * kPaintGroup; ++j) {
                 const uint32_t e = sky_list[j];
-                const uint32_t bx = e & 0xFFFFu, by = e >> 16;
+                const uint32_t bx = e & 0x7FFFu, by = e >> 16;
                 const uint32_t x = bx * 8u + (lane & 7u), y = tile_y0(P, by) + (lane >> 3);
                 if (x < P.width && y < P.y1) {
                     const size_t i_band = (size_t)(by * 8u + (lane >> 3)) * P.width + x;
@@ -1367,7 +1369,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
         const V3 up = v3(P.up[0], P.up[1], P.up[2]);
         const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
         const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
-        const uint32_t bx = entry & 0xFFFFu, by = entry >> 16;
+        const uint32_t bx = entry & 0x7FFFu, by = entry >> 16;
         const uint32_t ty0 = tile_y0(P, by);
         const uint32_t x = bx * 8u + (lane & 7u);
         const uint32_t y = ty0 + (lane >> 3);
@@ -1379,7 +1381,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
         // sphere colour wins unless it equals the sky colour.  Passes that cannot hit anything are not
         // traced (wave-uniform): no spheres at all, or no cube projecting into the tile.
         const bool skip_s = (P.n_spheres == 0u);
-        const bool skip_c = tile_has_no_cubes(P, bx, ty0);
+        const bool skip_c = (entry & kEntryNoCubes) != 0u;  // no cube projects into the tile (classification)
         V3 dir = v3(0.0f, 0.0f, 0.0f);
         if (!(skip_s && skip_c)) {
             float sx = (2.0f * (float)x) / width - 1.0f;
@@ -1465,7 +1467,7 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
 {
     const uint32_t cube = blockIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
-    if (cube == 0u && lane < 16u) T.queue[lane] = 0u;  // the work queue header of this frame's launch
+    if (cube == 0u && lane < 16u) T.queue[(T.qsel ^ 1u) * 16u + lane] = 0u;  // the queue header bank of the NEXT launch
     if (cube >= T.n_cubes) return;
     const float* rec = T.cube_filt + (size_t)cube * 4u;
     const double h = __builtin_fabs((double)rec[3]) + T.pad;
