@@ -1147,8 +1147,9 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                 // children (render.rs:154-193)
                 k_r = m.reflectivity;
                 k_t = m.transparency;
-                has_refl = hit_any && (k_r > 0.0f);
-                has_refr = hit_any && (k_t > 0.0f);
+                // the reference casts the secondary rays inside the light loop: without lights there are none
+                has_refl = hit_any && (k_r > 0.0f) && (nl != 0u);
+                has_refr = hit_any && (k_t > 0.0f) && (nl != 0u);
                 if (wave_any(has_refl || has_refr)) {
                     refl_d = vnormalize(reflect(vneg(d), hit.n));
                     refl_o = vadd(hit.p, vscale(hit.n, 1e-2f));
@@ -1200,8 +1201,8 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
         const float k_r = __builtin_bit_cast(float, fr[F_KR * 64]);
         const float k_t = __builtin_bit_cast(float, fr[F_KT * 64]);
         const bool hit_any = (sumf & kHitFlag) != 0u;
-        const bool has_refl = hit_any && (k_r > 0.0f);
-        const bool has_refr = hit_any && (k_t > 0.0f);
+        const bool has_refl = hit_any && (k_r > 0.0f) && (P.n_lights != 0u);
+        const bool has_refr = hit_any && (k_t > 0.0f) && (P.n_lights != 0u);
         uint32_t c0, c1 = 0u, h0 = 0u, h1 = 0u;
         if (((slotbits >> depth) & 1u) == 0u) {
             c0 = res;

@@ -235,3 +235,48 @@ def test_long_list_paths_forced(gpu_ctx, oracle_mod, scale, monkeypatch):
     f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, scene, 200, 120)
     assert_parity(gfb, gpl, ofb, opl, f"synthetic 900c, coherent scale {scale}")
     assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2])
+def test_max_depth_below_three(gpu_ctx, oracle_mod, water_scene, depth):
+    f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, water_scene, 192, 128, max_depth=depth)
+    assert_parity(gfb, gpl, ofb, opl, f"max_depth {depth}")
+    assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+
+
+@pytest.mark.parametrize("n_lights", [0, 1, 16])
+def test_light_counts(gpu_ctx, oracle_mod, default_scene, n_lights):
+    s = default_scene
+    lights = [rt.Light(rt.Vec3(-8.0 + k, 6.0 + 0.5 * k, 9.0 - 1.3 * k), 0x102030 * (k % 7 + 1) & 0xFFFFFF, 0.05 + 0.07 * k) for k in range(n_lights)]
+    sc = rt.make_scene(list(s.cubes), [], list(s.materials), lights, s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
+    f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, 160, 96)
+    assert_parity(gfb, gpl, ofb, opl, f"{n_lights} lights")
+    c = gpu_ctx.count_rays(f)
+    assert c.uniq_dict() == ocnt.uniq_dict()
+
+
+@pytest.mark.parametrize("name,eye,center,up", [
+    ("eye == center (NaN basis)", (0.0, 0.0, 10.0), (0.0, 0.0, 10.0), (0.0, 1.0, 0.0)),
+    ("up parallel to the view direction", (0.0, 12.0, 0.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)),
+])
+def test_degenerate_cameras(gpu_ctx, oracle_mod, default_scene, name, eye, center, up):
+    """Non-finite camera bases: every ray is NaN; the reference's compares then decide (a NaN ray passes
+    every slab compare), and the tile classification must stand aside."""
+    f, gfb, gpl, ofb, opl, _ = _both(gpu_ctx, oracle_mod, default_scene, 64, 40, camera=_cam(eye, center, up))
+    assert_parity(gfb, gpl, ofb, opl, name)
+
+
+def test_degenerate_spheres(gpu_ctx, oracle_mod, default_scene):
+    """Zero and negative radius, a sphere around the eye, far and near spheres, cubes behind spheres."""
+    s = default_scene
+    m = list(s.materials)
+    V = rt.Vec3
+    spheres = [rt.Sphere(100, V(0.0, 0.0, 0.0), 1.5, 0), rt.Sphere(101, V(2.5, 0.5, 1.0), -1.0, 1 % len(m)),
+               rt.Sphere(102, V(-2.5, 0.0, 0.0), 0.0, 2 % len(m)), rt.Sphere(103, V(0.0, 0.0, 10.0), 3.0, 3 % len(m)),
+               rt.Sphere(100, V(0.5, 2.5, -4.0), 1.25, 4 % len(m)), rt.Sphere(105, V(-300.0, 40.0, -500.0), 60.0, 5 % len(m))]
+    cubes = [rt.Cube(7, V(0.0, -2.5, 0.0), 3.0, 0), rt.Cube(8, V(3.0, 0.0, -3.0), 2.0, 6 % len(m))]
+    sc = rt.make_scene(cubes, spheres, m, list(s.lights), _cam((0.0, 0.0, 10.0), (0.0, 0.0, 0.0)), s.ambient_light, s.sky_0rgb, s.atlas)
+    for w, h in [(160, 120), (65, 33)]:
+        f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, w, h)
+        assert_parity(gfb, gpl, ofb, opl, f"degenerate spheres {w}x{h}")
+        assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
