@@ -32,6 +32,9 @@ WORKLOADS = {
     "minecraft_720p": ("default", {}, 1080, 720),
     "synthetic_4k": ("synthetic", {}, 3840, 2160),
     "minecraft_8k": ("default", {}, 7680, 4320),
+    # BASELINE.json config 5: camera orbit of the Minecraft scene at 8K, one degree of yaw per step
+    # (Camera::rotate_cam, reference src/camera.rs:61-86); rays/frame are counted on the first frame
+    "minecraft_8k_orbit": ("default", {"orbit": True}, 7680, 4320),
 }
 
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
@@ -56,6 +59,7 @@ def traffic_from_profile(workload):
 
 
 def make_scene(rt, kind, kwargs):
+    kwargs = {k: v for k, v in kwargs.items() if k != "orbit"}
     return rt.default_scene(**kwargs) if kind == "default" else rt.synthetic_scene(**kwargs)
 
 
@@ -142,7 +146,13 @@ def main():
         fg = FrameGather(H, W, world, rank, dev)
     out = fg.local  # [max_part_rows, W] int32, padded so every rank sends the same size
 
+    orbit = bool(kwargs.get("orbit"))
+    state = {"cam": scene.camera}
+
     def step():
+        if orbit:  # every rank advances the same camera
+            state["cam"] = rt.rotate_cam(state["cam"], 3.14159265358979 / 180.0, 0.0)
+            frame.camera = state["cam"]
         ctx.render_device(frame, out.data_ptr(), n_parts=world, part=rank)
         if world > 1:
             with torch.cuda.stream(ext):
@@ -184,6 +194,8 @@ def main():
     # ---- accounting (outside the timed region)
     result = None
     if rank == 0:
+        if orbit:
+            frame.camera = scene.camera
         total = ctx.count_rays(frame)
         mine = ctx.count_rays(frame, n_parts=world, part=0) if world > 1 else total
         rays_uniq, rays_ref = total.rays, total.ref_rays
