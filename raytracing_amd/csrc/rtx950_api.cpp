@@ -184,6 +184,12 @@ void fill_frame(const rt_ctx* ctx, const rt_frame* f, Params& p)
     p.y1 = f->y1;
     p.n_parts = 1u;
     p.part = 0u;
+    {
+        float ob = std::max(p.bound_max, p.sphere_bound_max);
+        for (int k = 0; k < 3; ++k) ob = std::max(ob, std::fabs(p.eye[k]));
+        ob += 1.0f;
+        p.origin_bound = (ob <= 0x1p20f) ? ob : 0x1p20f;  // NaN -> 2^20
+    }
     p.ambient = f->ambient_light;
     p.sky = f->sky_0rgb & 0x00FFFFFFu;
     p.max_depth = f->max_depth;

@@ -114,6 +114,10 @@ struct Params {
     uint32_t* tile_cost;
     uint32_t qsel;  // header bank of this launch (0/1): counts at words qsel * 16 + class; the other bank is zeroed for the next launch
     uint32_t grid_tx, grid_ty;
+    // upper bound of the origin coordinates of every ray of the frame: rays start at the eye or on an
+    // object's surface (+ 1e-2 along the normal); min(2^20, max(|eye|, object bounds) + 1).  A lane
+    // beyond it is treated like a non-finite one (the wave keeps every object).
+    float origin_bound;
     float ambient;
     uint32_t sky;
     uint32_t max_depth;

@@ -254,7 +254,7 @@ DEV RayPre ray_pre(const Params& P, V3 o, V3 d)
     // (a NaN ray passes every slab compare of the reference, which matters for shadows).
     const float bigd = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
     const bool finite = (d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (o.x == o.x) && (o.y == o.y) && (o.z == o.z);
-    q.wild = !(finite && bigd <= 0x1p40f && bigo <= 0x1p20f) || (P.fast_ok == 0u);
+    q.wild = !(finite && bigd <= 0x1p40f && bigo <= P.origin_bound) || (P.fast_ok == 0u);
     return q;
 }
 
@@ -582,23 +582,55 @@ struct CullPre {  // wave-uniform
     bool all;                   // some active ray is non-finite or huge: keep every cube
 };
 
-DEV CullPre cull_pre(bool active, V3 o, V3 d, bool wild, float bound_max)
+// max over the 64 lanes of two non-negative floats at once.  Each is rounded UP to its top 16 bits (a
+// bfloat16; ordered like an unsigned integer), the pair shares a dword, and v_pk_max_u16 does both lane
+// reductions in one DPP sweep; the results (<= 2^-7 above the true maxima, which only loosens the cull by
+// that much) come back as floats.  +inf rounds up to a NaN pattern: compares with it are false, which
+// keeps every cube, as it should.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+template <int CTRL, int ROW_MASK>
+DEV uint32_t dpp_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+DEV uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+DEV void wave_max2(float a, float b, float& out_a, float& out_b)
+{
+    const uint32_t ua = (__builtin_bit_cast(uint32_t, a) >> 16) + 1u, ub = (__builtin_bit_cast(uint32_t, b) >> 16) + 1u;
+    uint32_t v = (ua << 16) | (ub & 0xFFFFu);
+    v = pk_max_u16(v, dpp_u<0x111, 0xf>(v));
+    v = pk_max_u16(v, dpp_u<0x112, 0xf>(v));
+    v = pk_max_u16(v, dpp_u<0x114, 0xf>(v));
+    v = pk_max_u16(v, dpp_u<0x118, 0xf>(v));
+    v = pk_max_u16(v, dpp_u<0x142, 0xa>(v));
+    v = pk_max_u16(v, dpp_u<0x143, 0xc>(v));
+    const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    out_a = __builtin_bit_cast(float, r & 0xFFFF0000u);
+    out_b = __builtin_bit_cast(float, r << 16);
+}
+
+// origin_bound: an upper bound of every active lane's origin coordinates (Params::origin_bound; lanes
+// beyond it are `wild`), used where the wave's largest origin magnitude used to be reduced.
+DEV CullPre cull_pre(bool active, V3 o, V3 d, bool wild, float bound_max, float origin_bound)
 {
     CullPre c;
     const unsigned long long am = wave_ballot(active);
     const uint32_t ref = am ? (uint32_t)__builtin_ctzll(am) : 0u;
     c.all = wave_any(active && wild);
-    const float wxy = o.x * d.y - o.y * d.x, wyz = o.y * d.z - o.z * d.y, wzx = o.z * d.x - o.x * d.z;
+    // moments (only ever compared against bounds with slack: FMA is fine here)
+    const float wxy = __builtin_fmaf(o.x, d.y, -(o.y * d.x)), wyz = __builtin_fmaf(o.y, d.z, -(o.z * d.y)), wzx = __builtin_fmaf(o.z, d.x, -(o.x * d.z));
     c.dxc = readlane_f(d.x, ref); c.dyc = readlane_f(d.y, ref); c.dzc = readlane_f(d.z, ref);
     c.wxyc = readlane_f(wxy, ref); c.wyzc = readlane_f(wyz, ref); c.wzxc = readlane_f(wzx, ref);
     const float z = 0.0f;
-    // three wave reductions: one radius for the direction, one for the moment, one origin magnitude
+    // one sweep: radius of the directions and of the moments around the reference lane
     const float dr = __builtin_fmaxf(__builtin_fabsf(d.x - c.dxc), __builtin_fmaxf(__builtin_fabsf(d.y - c.dyc), __builtin_fabsf(d.z - c.dzc)));
     const float wr = __builtin_fmaxf(__builtin_fabsf(wxy - c.wxyc), __builtin_fmaxf(__builtin_fabsf(wyz - c.wyzc), __builtin_fabsf(wzx - c.wzxc)));
-    const float om = __builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fmaxf(__builtin_fabsf(o.y), __builtin_fabsf(o.z)));
-    c.dr = wave_max(active ? dr : z);
-    const float wrm = wave_max(active ? wr : z);
-    const float omax = wave_max(active ? om : z);
+    float wrm;
+    wave_max2(active ? dr : z, active ? wr : z, c.dr, wrm);
+    const float omax = origin_bound;
     const float ax = __builtin_fabsf(c.dxc) + c.dr, ay = __builtin_fabsf(c.dyc) + c.dr, az = __builtin_fabsf(c.dzc) + c.dr;
     c.sxy = ax + ay; c.syz = ay + az; c.szx = az + ax;
     c.ax = ax; c.ay = ay; c.az = az;
@@ -608,8 +640,8 @@ DEV CullPre cull_pre(bool active, V3 o, V3 d, bool wild, float bound_max)
     // 2^-17 (B + O + 1) max(D, 1) = 128 u (...) covers both several times over.
     const float slack = 0x1p-17f * (bound_max + omax + 1.0f) * __builtin_fmaxf(ax + ay + az, 1.0f);
     c.wr = wrm + slack;
-    c.omax = omax;
     c.wr_raw = wrm;
+    c.omax = omax;
     return c;
 }
 
@@ -889,7 +921,7 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
     const RayPre q = ray_pre(P, o, d);
     st.tol = q.tol;
     st.div_ok = q.div_ok;
-    const CullPre cp = cull_pre(active, o, d, q.wild, P.bound_max);
+    const CullPre cp = cull_pre(active, o, d, q.wild, P.bound_max, P.origin_bound);
     if constexpr (LARGE) {
         // how much the wave's spread inflates every cube in cull_test, against the cubes' own size (wave-uniform)
         const bool coherent = cp.all || !(__builtin_fmaf(2.0f * P.bound_max, cp.dr, cp.wr_raw) > P.coherent_thr);
@@ -908,12 +940,12 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
 // 7.5 u |oc|^2 / r + 3 u r cannot be reported as a hit; |oc|^2 <= 3 (O + B)^2 with O, B the largest origin
 // and sphere coordinate.  The box is therefore inflated by 2^-17 (O + B + 1)^2 / r (6x that bound; r -> 0
 // gives an infinite box: always a candidate).
-DEV bool ray_wild(V3 o, V3 d)
+DEV bool ray_wild(const Params& P, V3 o, V3 d)
 {
     const float bigd = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
     const float bigo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
     const bool finite = (d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (o.x == o.x) && (o.y == o.y) && (o.z == o.z);
-    return !(finite && bigd <= 0x1p40f && bigo <= 0x1p20f);
+    return !(finite && bigd <= 0x1p40f && bigo <= P.origin_bound);
 }
 
 // NEAREST: render.rs:87-101 over the sphere list (strict <, list order).  SHADOW: render.rs:44-70, the
@@ -923,7 +955,7 @@ DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_
 {
     const uint32_t n = P.n_spheres;
     if (n == 0u) return;
-    const CullPre cp = cull_pre(active, o, d, ray_wild(o, d) || (P.sphere_ok == 0u), P.sphere_bound_max);
+    const CullPre cp = cull_pre(active, o, d, ray_wild(P, o, d) || (P.sphere_ok == 0u), P.sphere_bound_max, P.origin_bound);
     const float grow = 0x1p-17f * (cp.omax + P.sphere_bound_max + 1.0f) * (cp.omax + P.sphere_bound_max + 1.0f);
     const uint32_t lane = threadIdx.x & 63u;
     const f32x4* filt = (const f32x4*)P.sphere_filt;
