@@ -475,6 +475,7 @@ DEV V3 refract(V3 i, V3 n, float eta_t)
 // f32::powf.  The reference calls glibc powf (error < 1 ulp, correctly rounded in all but a
 // vanishing fraction of cases); evaluating in f64 and rounding once reproduces that far more
 // closely than the 1-2 ulp f32 device routine.  Two calls per shaded hit: not a hot spot.
+DEV bool wave_any_early(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 DEV float powf_like_libm(float x, float y)
 {
     // exact special cases of powf first (most shaded points have a clamped base of exactly 0):
@@ -489,7 +490,8 @@ DEV float powf_like_libm(float x, float y)
     // A 3-instruction estimate exp2(y*log2 x) (v_log_f32/v_exp_f32, 1 ulp each; relative error of the
     // result <= ~2^-22 * (1 + |y log2 x|) < 1e-3 for |y log2 x| < 2^12) proves that for most pixels, and
     // the estimate itself (< 2^-9) is then returned: it yields the same zeros as the exact value.
-    if (full && x > 0.0f && x < 1.0f && y > 0.0f) {
+    const bool est_ok = full && x > 0.0f && x < 1.0f && y > 0.0f;
+    if (wave_any_early(est_ok) && est_ok) {
         const float e = y * __builtin_amdgcn_logf(x);
         const float est = __builtin_amdgcn_exp2f(e);
         if (est < 0x1p-9f && e > -4096.0f) {
@@ -1172,7 +1174,11 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
                     const Col diffuse = col_mul(col_mul(tx_a, diffuse_intensity), light_intensity);
                     const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m.specular);
-                    const Col specular = col_mul(col_mul(col_mul(col_from_hex(L.color_0rgb), m.albedo1), spec_i), light_intensity);
+                    // (c * spec_i) truncates to 0 in every channel when spec_i < 1/256: the usual case away from
+                    // highlights, and then the specular term is exactly black
+                    Col specular = Col{0.0f, 0.0f, 0.0f};
+                    if (wave_any(!(spec_i < 0x1p-8f)))
+                        specular = col_mul(col_mul(col_mul(col_from_hex(L.color_0rgb), m.albedo1), spec_i), light_intensity);
                     sum = col_add(sum, col_mul(col_add(diffuse, specular), k_ds));
                 }
                 PROF_MARK(PH_SHADE);
