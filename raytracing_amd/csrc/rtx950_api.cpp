@@ -59,6 +59,7 @@ struct rt_ctx {
     uint32_t* d_cost = nullptr;
     size_t cost_cap = 0;
     uint32_t launch_seq = 0;   // selects the queue header bank
+    uint32_t max_workgroups = 24576;  // grid of render_kernel: 6x the resident single-wave workgroups of an MI355X (swept: 12K..32K within 3 %)
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded pairs since last query
@@ -333,7 +334,7 @@ int launch_timed(rt_ctx* ctx, const Params& p, int variant)
         }
         HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
     }
-    e = (hipError_t)launch_render(p, variant, (void*)ctx->stream);
+    e = (hipError_t)launch_render(p, variant, (void*)ctx->stream, ctx->max_workgroups);
     if (e != hipSuccess) return fail_hip(ctx, e, "render kernel launch");
     if (ctx->timing) {
         HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
@@ -370,6 +371,7 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
         delete c;
         return fail_hip(nullptr, e, "hipMalloc(counters)");
     }
+    if (const char* g = getenv("RTX950_GRID")) { long v = atol(g); if (v > 0 && v < (1l << 30)) c->max_workgroups = (uint32_t)v; }  // tuning experiments
     *out_ctx = c;
     return RT_OK;
 }
@@ -763,7 +765,7 @@ int rt_count_rays_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     if ((rc = prepare(ctx, p)) != RT_OK) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
     if ((rc = listing(ctx, p, kVariantCount)) != RT_OK) return rc;
-    hipError_t e = (hipError_t)launch_render(p, kVariantCount, (void*)ctx->stream);
+    hipError_t e = (hipError_t)launch_render(p, kVariantCount, (void*)ctx->stream, ctx->max_workgroups);
     if (e != hipSuccess) return fail_hip(ctx, e, "count kernel launch");
     unsigned long long h[10];
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

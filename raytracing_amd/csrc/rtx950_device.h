@@ -156,9 +156,9 @@ enum KernelVariant { kVariantRender = 0, kVariantDebug = 1, kVariantCount = 2 };
 // Launches the render kernel for rows [y0,y1) on `stream` (hipStream_t passed as void*).
 // Returns a hipError_t as int.
 // launch_queue: lists the tiles that need tracing and paints the others (build_queue); launch_render:
-// one single-wave workgroup per possible tile.  Both return a hipError_t.
+// at most max_workgroups single-wave workgroups striding over the queue.  Both return a hipError_t.
 int launch_queue(const Params& p, int variant, void* stream);
-int launch_render(const Params& p, int variant, void* stream);
+int launch_render(const Params& p, int variant, void* stream, uint32_t max_workgroups);
 int launch_classify(const TileParams& t, void* stream);
 // selftest_division: blocks x 256 threads x iters operand pairs; d_out[0] += mismatches, d_out[1] += cases
 int launch_selftest_division(uint32_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out, void* stream);

@@ -1354,9 +1354,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
     Totals cnt;
 #pragma unroll
     for (int k = 0; k < 10; ++k) cnt.v[k] = 0ull;
+    // The queue is final (build_queue has completed).  Item i = the i-th traced tile in heaviest-first
+    // order, then the paint groups; a workgroup takes items blockIdx.x, + gridDim.x, ...: with a grid of a
+    // few times the resident workgroups the dispatcher still balances the heavy first items, the later
+    // (light) ones ride along, and there are no surplus workgroups to launch (one per possible tile cost
+    // the 4K frame 30 us of dispatching at its end).
+    for (uint32_t item = blockIdx.x;; item += gridDim.x) {
     const unsigned long long t_start = __builtin_readcyclecounter();
-    // the queue is final: build_queue has completed
-    uint32_t idx = blockIdx.x, entry = 0xFFFFFFFFu;
+    uint32_t idx = item, entry = 0xFFFFFFFFu;
     bool painted = false;
     {
         const uint32_t tiles = P.grid_tx * P.grid_ty;
@@ -1375,6 +1380,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
             // colour, "no hit" planes) and counts the rays the reference would still have cast for them.
             KCONST uint32_t* sky_list = q + kQueueBase + kCostClasses * tiles;
             const uint32_t n_sky = q[P.qsel * 16u + kCostClasses];
+            if (idx * kPaintGroup >= n_sky) break;  // no items left (every wave gets here: items only grow)
             const uint32_t no_hash = hmix(kHashBasis, kNoHit);
             const uint32_t px_hash = hmix(hmix(kHashBasis, no_hash), no_hash);
             for (uint32_t j = idx * kPaintGroup; j < n_sky && j < (idx + 1u) * kPaintGroup; ++j) {
@@ -1480,6 +1486,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
         }
 #endif
     }
+    }  // items
     if constexpr (COUNT) {
         // wave reduction, then one atomic per wave and counter
 #pragma unroll
@@ -1618,13 +1625,13 @@ int launch_queue(const Params& p, int variant, void* stream)
     return (int)hipGetLastError();
 }
 
-int launch_render(const Params& p, int variant, void* stream)
+int launch_render(const Params& p, int variant, void* stream, uint32_t max_workgroups)
 {
     const uint32_t tiles = p.grid_tx * p.grid_ty;
     if (tiles == 0u) return (int)hipSuccess;
-    // single-wave workgroups: one per traced tile, then one per kPaintGroup painted tiles; the split is
-    // only known on the device, so the grid covers both extremes and the surplus exits at once
-    dim3 grid(tiles + (tiles + kPaintGroup - 1u) / kPaintGroup, 1u, 1u), block(64u, 1u, 1u);
+    // single-wave workgroups striding over the items (traced tiles, then paint groups)
+    const uint32_t items = tiles + (tiles + kPaintGroup - 1u) / kPaintGroup;
+    dim3 grid(items < max_workgroups ? items : max_workgroups, 1u, 1u), block(64u, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
     const bool large = p.n_chunks > 0u;  // long cube list: Morton-ordered stream, chunk boxes, BVH
     switch (variant) {
