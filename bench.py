@@ -46,6 +46,14 @@ def algorithmic_flops(c, n_lights):
     return 26.0 * c.cube_tests + 25.0 * c.sphere_tests + 60.0 * n_lights * c.shaded_hits
 
 
+def profile_field(workload, field):
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload, {}).get(field)
+    except (OSError, ValueError):
+        return None
+
+
 def traffic_from_profile(workload):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this same
     command (profiles/traffic.json, written by tools/summarize_pmc.py: 2 x FETCH_SIZE KB + WRITE_SIZE KB
@@ -232,7 +240,10 @@ def main():
                 "kernel": "render_kernel<false,false>", "kernel_avg_ms": kern_ms, "launches_timed": kern_n,
                 "algorithmic_flops_per_launch": flops_launch,
                 "frac_of_nonfma_lane_op_ceiling": achieved_tf / PEAK_LANE_OPS_T,
-                "note": "algorithmic FP32 ops: 26/ray-cube test + 25/ray-sphere test + 60*lights/shaded hit (SURVEY 8d), rank 0's launch",
+                # executed view from the committed rocprofv3 PMC pass of this command (profiles/traffic.json)
+                "valu_busy_frac_pmc": profile_field(args.workload, "valu_busy_frac"),
+                "valu_insts_per_launch_pmc": profile_field(args.workload, "valu_insts_per_launch"),
+                "note": "algorithmic FP32 ops of the reference's brute-force walk: 26/ray-cube test + 25/ray-sphere test + 60*lights/shaded hit (SURVEY 8d), rank 0's launch; the kernel proves most tests fail without executing them, so frac can exceed 1 (executed view: valu_busy_frac_pmc)",
             },
         }
         if world == 1 and args.cpu_seconds > 0:

@@ -55,6 +55,11 @@ if traffic_out and "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     t[workload] = {
         "kernel": needle, "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
         "hbm_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+        # executed view: wave64 VALU instructions per launch and the share of SIMD issue time they take
+        # (SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs; 256 CUs x 4 SIMDs)
+        "valu_insts_per_launch": vals.get("SQ_INSTS_VALU"),
+        "valu_busy_frac": (vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0))
+                          if "SQ_ACTIVE_INST_VALU" in vals and vals.get("GRBM_GUI_ACTIVE") else None,
         "source": os.path.basename(os.path.normpath(root)),
     }
     json.dump(t, open(traffic_out, "w"), indent=1, sort_keys=True)
