@@ -1023,9 +1023,9 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
 // First object in array order, among those whose id differs from the impact object's
 // (render.rs:113), whose ray_intersect returns Some.  Not the nearest one.
 template <bool COUNT, bool LARGE>
-DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V3 light_pos, uint32_t impact_id, uint32_t& blocker, Counters& cnt PROF_ARG)
+DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V3 light_pos, V3 dir, uint32_t impact_id, uint32_t& blocker, Counters& cnt PROF_ARG)
 {
-    const V3 dir = vnormalize(vsub(light_pos, origin));
+    // dir = normalize(light_pos - origin) (render.rs:46), the caller's light_dir: the same expression
     blocker = kNoHit;
     float sdist = 0.0f;
     if constexpr (COUNT) cnt.shadow_rays += active ? 1u : 0u;
@@ -1168,7 +1168,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     uint32_t blocker;
                     PROF_MARK(PH_SHADE);
                     PROF_KIND(depth * 2u + 1u);
-                    const float shadow = shadow_query<COUNT, LARGE>(P, pass, hit_any, hit.p, lp, hit.id, blocker, cnt PROF_PASS);
+                    const float shadow = shadow_query<COUNT, LARGE>(P, pass, hit_any, hit.p, lp, light_dir, hit.id, blocker, cnt PROF_PASS);
                     if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
                     const float light_intensity = L.intensity * (1.0f - shadow);
                     const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
