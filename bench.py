@@ -3,7 +3,8 @@
 
 A step = one frame of the workload rendered through the C-ABI (rt_render_device_part): at N>1 the
 frame's 16-row blocks are dealt round-robin to the ranks (strong scaling, total work fixed) and each
-rank's compact band is gathered to GPU0 over RCCL/xGMI inside the timed region.
+rank's compact band (the rows that can hold geometry) is gathered to GPU0 over RCCL/xGMI inside the
+timed region, overlapped with the rendering of the next frame.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -147,12 +148,16 @@ def main():
     frame = scene.frame(W, H)
     n_lights = len(scene.lights)
 
-    from raytracing_amd.multigpu import FrameGather
-    # order the gather (and rank 0's row scatter) after the render on the library's own stream
+    from raytracing_amd.multigpu import FrameGather, FramePipeline
+    # the library's own stream as a torch stream: the gather of a frame is ordered after its render by events
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
     with torch.cuda.stream(ext):
-        fg = FrameGather(H, W, world, rank, dev)
+        piped = world > 1 or bool(os.environ.get("RTX950_BENCH_PIPELINE"))  # the variable: N>1 plumbing on one GPU, for testing
+        fg = FrameGather(H, W, world, rank, dev, depth=2 if piped else 1)
     out = fg.local  # [max_part_rows, W] int32, padded so every rank sends the same size
+    # N > 1: frame f+1 renders while frame f is gathered to GPU0 (two message buffers, gather stream);
+    # every frame is whole on GPU0 before the timed region ends (sync() below waits for all streams)
+    pipe = FramePipeline(fg, lambda buf: ctx.render_device(frame, buf.data_ptr(), n_parts=world, part=rank), ext) if piped else None
 
     orbit = bool(kwargs.get("orbit"))
     state = {"cam": scene.camera}
@@ -161,10 +166,12 @@ def main():
         if orbit:  # every rank advances the same camera
             state["cam"] = rt.rotate_cam(state["cam"], 3.14159265358979 / 180.0, 0.0)
             frame.camera = state["cam"]
-        ctx.render_device(frame, out.data_ptr(), n_parts=world, part=rank)
-        if world > 1:
-            with torch.cuda.stream(ext):
-                fg.gather()  # RCCL gather to GPU0 + scatter of the 16-row blocks into frame order
+        if pipe is None:
+            ctx.render_device(frame, out.data_ptr())
+        else:
+            # render this rank's blocks, then (gather stream) RCCL gather of the rows that can hold geometry
+            # to GPU0 + scatter into frame order; GPU0 paints the sky rows itself (rt_frame_row_extent)
+            pipe.submit(ctx.row_extent(frame), frame.sky_0rgb)
 
     def sync():
         ctx.sync()
@@ -227,7 +234,7 @@ def main():
             "config": {
                 "workload": args.workload, "width": W, "height": H, "n_cubes": scene.n_cubes, "n_spheres": scene.n_spheres,
                 "n_lights": n_lights, "max_depth": 3,
-                "partition": f"16-row blocks round-robin over {world} GPU(s), compact bands gathered to GPU0 (RCCL)" if world > 1
+                "partition": f"16-row blocks round-robin over {world} GPU(s); rows that can hold geometry gathered to GPU0 (RCCL), pipelined one frame deep" if world > 1
                              else "whole frame on one GPU",
                 "rays_per_frame_unique": rays_uniq, "rays_per_frame_reference": rays_ref,
                 "mrays_per_s_reference_accounting": rays_ref * args.steps / elapsed / 1e6,

@@ -210,6 +210,16 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
 /* Number of rows part `part` of `n_parts` holds for a band of `rows` rows (16-row blocks). */
 uint32_t rt_part_rows(uint32_t rows, uint32_t n_parts, uint32_t part);
 
+/* Rows of the band that can hold anything but sky: on return every pixel of rows [y0, *out_y_first)
+ * and [*out_y_end, y1) of the frame is the sky colour in the rendered image (except the reference's
+ * unpainted pixel i == width, see rt_render), so a multi-GPU host need not move those rows: GPU0
+ * fills them itself.  Computed on the host from the uploaded scene (no device work, no
+ * synchronisation) with the projection the tile classification uses: conservative, never exact; the
+ * whole band when the scene has spheres or the camera is irregular; y_first == y_end == y0 when
+ * nothing projects into the band.  No reference counterpart (the reference has one address space;
+ * its pixel loop is reference src/render.rs:248-306). */
+int rt_frame_row_extent(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_y_first, uint32_t* out_y_end);
+
 /* Wait for all work enqueued on the context's stream.  No reference counterpart (the reference
  * is synchronous). */
 int rt_sync(rt_ctx* ctx);

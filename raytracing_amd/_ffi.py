@@ -136,6 +136,7 @@ ABI_SYMBOLS = {
     "rt_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_selftest_division": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rt_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rt_frame_row_extent": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 
 HOST_SYMBOLS = {

@@ -212,6 +212,12 @@ class Context:
         self._check(self._lib.rt_kernel_time_ms(self._ctx, C.byref(avg), C.byref(n)))
         return avg.value, n.value
 
+    def row_extent(self, frame: Frame):
+        """rt_frame_row_extent: (y_first, y_end); rows of the band outside it are sky (host-side bound)."""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(self._lib.rt_frame_row_extent(self._ctx, C.byref(frame), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def stream(self) -> int:
         s = C.c_void_p()
         self._check(self._lib.rt_get_stream(self._ctx, C.byref(s)))

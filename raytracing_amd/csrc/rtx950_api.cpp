@@ -30,6 +30,8 @@ struct rt_ctx {
     bool has_scene = false;
     CubeRec* d_cubes = nullptr;
     float* d_cube_filt = nullptr;
+    std::vector<float> h_cube_box;  // centre xyz + |half size| per cube, list order (rt_frame_row_extent)
+    size_t h_n_spheres = 0;
     uint32_t* d_cube_id = nullptr;
     uint32_t* d_cube_perm = nullptr;
     BvhNode* d_bvh = nullptr;
@@ -220,6 +222,31 @@ int ensure(rt_ctx* ctx, uint32_t** buf, size_t* cap, size_t need)
     return RT_OK;
 }
 
+// Camera part of the cube projection (classify_tiles on the device, rt_frame_row_extent on the host):
+// the f32 basis of the frame in f64, its determinant, the padding.  False on anything irregular
+// (non-finite camera or bounds, skewed basis): then nothing may be concluded from projections.
+bool projection_setup(const Params& p, TileParams& t)
+{
+    std::memset(&t, 0, sizeof(t));
+    bool regular = std::isfinite(p.bound_max);
+    double mag = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        t.eye[k] = p.eye[k]; t.right[k] = p.right[k]; t.up[k] = p.up[k]; t.fwd[k] = p.fwd[k];
+        if (!std::isfinite(t.eye[k]) || !std::isfinite(t.right[k]) || !std::isfinite(t.up[k]) || !std::isfinite(t.fwd[k])) regular = false;
+        mag = std::max(mag, std::fabs(t.eye[k]));
+    }
+    mag = std::max(mag, (double)p.bound_max);
+    const double* r = t.right; const double* u = t.up; const double* f = t.fwd;
+    const double det = r[0] * (u[1] * f[2] - u[2] * f[1]) - r[1] * (u[0] * f[2] - u[2] * f[0]) + r[2] * (u[0] * f[1] - u[1] * f[0]);
+    if (!(std::fabs(det) > 0.5 && std::fabs(det) < 2.0)) regular = false;  // an orthonormal basis has |det| = 1
+    if (!regular) return false;
+    t.inv_det = 1.0 / det;
+    t.pad = mag * 0x1p-17;  // >= 64 ulp of the largest coordinate involved
+    t.aspect = (double)((float)p.width / (float)p.height);
+    t.width = p.width; t.height = p.height;
+    return true;
+}
+
 // Per-launch preparation on the context's stream: the work queue (sized for the launch's tile grid, its
 // header zeroed) and the tile stamps (classify_tiles).  On anything irregular (non-finite camera, skewed
 // basis, non-finite bounds) p.tile_stamps stays null and every tile is traced.
@@ -260,28 +287,13 @@ int prepare(rt_ctx* ctx, Params& p)
     p.tile_cost = ctx->d_cost;
 
     TileParams t;
-    std::memset(&t, 0, sizeof(t));
-    bool regular = std::isfinite(p.bound_max);
-    double mag = 1.0;
-    for (int k = 0; k < 3; ++k) {
-        t.eye[k] = p.eye[k]; t.right[k] = p.right[k]; t.up[k] = p.up[k]; t.fwd[k] = p.fwd[k];
-        if (!std::isfinite(t.eye[k]) || !std::isfinite(t.right[k]) || !std::isfinite(t.up[k]) || !std::isfinite(t.fwd[k])) regular = false;
-        mag = std::max(mag, std::fabs(t.eye[k]));
-    }
-    mag = std::max(mag, (double)p.bound_max);
-    const double* r = t.right; const double* u = t.up; const double* f = t.fwd;
-    const double det = r[0] * (u[1] * f[2] - u[2] * f[1]) - r[1] * (u[0] * f[2] - u[2] * f[0]) + r[2] * (u[0] * f[1] - u[1] * f[0]);
-    if (!(std::fabs(det) > 0.5 && std::fabs(det) < 2.0)) regular = false;  // an orthonormal basis has |det| = 1
-    if (!regular) {
+    if (!projection_setup(p, t)) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue + (p.qsel ^ 1u) * 16u, 0, 16 * sizeof(uint32_t), ctx->stream));
         return RT_OK;
     }
     t.cube_filt = p.cube_filt;
     t.n_cubes = p.n_cubes;
-    t.inv_det = 1.0 / det;
-    t.pad = mag * 0x1p-17;  // >= 64 ulp of the largest coordinate involved
-    t.aspect = (double)((float)p.width / (float)p.height);
-    t.width = p.width; t.height = p.height; t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y;
+    t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y;
     t.queue = ctx->d_queue;
     t.qsel = p.qsel;
     // fine stamps per 8x8 tile, then coarse stamps per block of 8x8 tiles
@@ -486,6 +498,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
         hf[4 * j + 3] = std::fabs(c.size / 2.0f);  // min > max (negative size) is the same box to the slab test (lib.rs:29-35 sorts the two t)
         hid[j] = c.id;
     }
+    ctx->h_cube_box.resize(n_cubes * 4);
+    for (size_t i = 0; i < n_cubes; ++i) {
+        ctx->h_cube_box[4 * i + 0] = cubes[i].center.x; ctx->h_cube_box[4 * i + 1] = cubes[i].center.y;
+        ctx->h_cube_box[4 * i + 2] = cubes[i].center.z; ctx->h_cube_box[4 * i + 3] = std::fabs(cubes[i].size / 2.0f);
+    }
+    ctx->h_n_spheres = n_spheres;
     const size_t n_chunks = large ? (n_cubes + 63) / 64 : 0;
     const size_t n_box = ((n_chunks + 63) / 64) * 64 + 64;
     std::vector<float> hbox(n_box * 8, 0.0f);
@@ -857,6 +875,51 @@ int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches)
     *out_avg_ms = ctx->events.empty() ? 0.0 : total / (double)ctx->events.size();
     for (auto& ev : ctx->events) ctx->event_pool.push_back(ev);
     ctx->events.clear();
+    return RT_OK;
+}
+
+// Host-side twin of classify_tiles, rows only: the same padded f64 projection of every cube's corners.
+int rt_frame_row_extent(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_y_first, uint32_t* out_y_end)
+{
+    int rc = check_frame(ctx, frame);
+    if (rc != RT_OK) return rc;
+    if (!out_y_first || !out_y_end) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
+    *out_y_first = frame->y0;
+    *out_y_end = frame->y1;
+    if (ctx->h_n_spheres != 0) return RT_OK;  // the sphere pass is traced everywhere
+    Params p;
+    fill_frame(ctx, frame, p);
+    TileParams t;
+    if (!projection_setup(p, t)) return RT_OK;
+    const double* r = t.right; const double* u = t.up; const double* f = t.fwd;
+    double lo = 1e300, hi = -1e300;
+    const size_t n = ctx->h_cube_box.size() / 4;
+    for (size_t i = 0; i < n; ++i) {
+        const float* rec = &ctx->h_cube_box[4 * i];
+        const double h = std::fabs((double)rec[3]) + t.pad;
+        for (unsigned corner = 0; corner < 8u; ++corner) {
+            double q[3];
+            for (int k = 0; k < 3; ++k) q[k] = (double)rec[k] + (((corner >> k) & 1u) ? h : -h) - t.eye[k];
+            // q = a right + b up + c fwd (Cramer); only b and c matter for the row
+            const double b = (r[0] * (q[1] * f[2] - q[2] * f[1]) - r[1] * (q[0] * f[2] - q[2] * f[0]) + r[2] * (q[0] * f[1] - q[1] * f[0])) * t.inv_det;
+            const double c = (r[0] * (u[1] * q[2] - u[2] * q[1]) - r[1] * (u[0] * q[2] - u[2] * q[0]) + r[2] * (u[0] * q[1] - u[1] * q[0])) * t.inv_det;
+            const double len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+            const double py = (1.0 - b / c) * (double)t.height * 0.5;
+            // a corner beside or behind the eye (the slab test is a line test), or NaN: no conclusion
+            if (!(c > 1e-3 * len) || !(c > 16.0 * t.pad) || !(std::fabs(py) < 1e9)) return RT_OK;
+            lo = std::min(lo, py);
+            hi = std::max(hi, py);
+        }
+    }
+    // same two-pixel padding as the tile rectangles; the last row that can hold geometry is ceil(hi) + 2
+    const double first = std::floor(lo) - 2.0, last = std::ceil(hi) + 2.0;
+    uint32_t y_first = frame->y0, y_end = frame->y0;  // nothing projects into the band: empty extent
+    if (n != 0 && last >= (double)frame->y0 && first <= (double)frame->y1 - 1.0) {
+        y_first = first <= (double)frame->y0 ? frame->y0 : (uint32_t)first;
+        y_end = last >= (double)frame->y1 - 1.0 ? frame->y1 : (uint32_t)last + 1u;
+    }
+    *out_y_first = y_first;
+    *out_y_end = y_end;
     return RT_OK;
 }
 

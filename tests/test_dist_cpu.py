@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 gloo run of the band partition + gather + reassembly (no GPU)."""
+"""N>1 path on CPU: world_size-2/3 gloo runs of the block partition + gather + reassembly (no GPU)."""
 import os
 import socket
 import sys
@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracing_amd import multigpu  # noqa: E402
 
+SKY = 0x87CEEB
+
 
 def _free_port():
     s = socket.socket()
@@ -22,15 +24,27 @@ def _free_port():
     return p
 
 
+def _image(rows, width, extent, tag):
+    """Stand-in for the rendered frame: sky outside the extent, (tag, row, column) inside, and the
+    reference's unpainted pixel i == width."""
+    img = ((np.arange(rows)[:, None] * 1000 + np.arange(width)[None, :]) * 16 + tag).astype(np.int32)
+    if extent is not None:
+        img[: extent[0]] = SKY
+        img[extent[1]:] = SKY
+    if rows > 1:
+        img[1, 0] = 0
+    return img
+
+
 def _worker(rank, world, port, rows, width, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = multigpu.FrameGather(rows, width, world, rank, torch.device("cpu"))
-    # stand-in for rt_render_device_part: pixel value encodes (frame row, column)
+    # stand-in for rt_render_device_part: this rank's rows of the image, compact
     idx = multigpu.part_row_indices(rows, world, rank)
     g.local.zero_()
-    g.local[: len(idx)] = torch.from_numpy((idx[:, None] * 100000 + np.arange(width)[None, :]).astype(np.int32))
+    g.local[: len(idx)] = torch.from_numpy(_image(rows, width, None, 0)[idx])
     frame = g.gather()
     if rank == 0:
         np.save(out_path, frame.numpy())
@@ -42,9 +56,65 @@ def _worker(rank, world, port, rows, width, out_path):
 def test_gather_reassembles_frame(tmp_path, rows, width, world):
     out = str(tmp_path / "frame.npy")
     mp.spawn(_worker, args=(world, _free_port(), rows, width, out), nprocs=world, join=True)
-    frame = np.load(out)
-    expect = (np.arange(rows)[:, None] * 100000 + np.arange(width)[None, :]).astype(np.int32)
-    assert np.array_equal(frame, expect)
+    assert np.array_equal(np.load(out), _image(rows, width, None, 0))
+
+
+def _extents(rows):
+    """A camera move as the extents see it: geometry rows shrink, grow, vanish, fill the frame."""
+    return [(rows // 4, 3 * rows // 4), (rows // 4, 3 * rows // 4), (rows // 3, rows // 2), (0, rows), (5, 6) if rows > 6 else (0, 1),
+            (rows // 2, rows // 2), None, (2, rows - 1) if rows > 3 else (0, rows), (0, 1), (rows - 1, rows)]
+
+
+def _pipeline_worker(rank, world, port, rows, width, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = multigpu.FrameGather(rows, width, world, rank, torch.device("cpu"), depth=2)
+    idx = multigpu.part_row_indices(rows, world, rank)
+    state = {}
+
+    def render(buf):
+        buf.fill_(-1)  # rows past the part stay garbage: they must never reach the frame
+        buf[: len(idx)] = torch.from_numpy(_image(rows, width, state["extent"], state["tag"])[idx])
+
+    pipe = multigpu.FramePipeline(g, render)
+    frames = []
+    for tag, extent in enumerate(_extents(rows)):
+        state.update(extent=extent, tag=tag)
+        pipe.submit(extent, SKY if extent is not None else None)
+        if rank == 0:
+            frames.append(g.frame.numpy().copy())
+    pipe.drain()
+    if rank == 0:
+        np.save(out_path, np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows,width,world", [(720, 16, 2), (45, 7, 2), (100, 5, 3), (16, 3, 1)])
+def test_pipeline_sends_only_the_extent(tmp_path, rows, width, world):
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), rows, width, out), nprocs=world, join=True)
+    frames = np.load(out)
+    for tag, extent in enumerate(_extents(rows)):
+        assert np.array_equal(frames[tag], _image(rows, width, extent, tag)), (tag, extent)
+
+
+def test_message_window_covers_the_extent():
+    rng = np.random.default_rng(7)
+    for _ in range(300):
+        rows = int(rng.integers(1, 400))
+        n = int(rng.integers(1, 9))
+        y0 = int(rng.integers(0, rows))
+        y1 = int(rng.integers(y0 + 1, rows + 1))
+        a, b, fa, fb = multigpu.message_window(rows, n, (y0, y1))
+        assert 0 <= a < b <= multigpu.max_part_rows(rows, n)
+        assert fa <= y0 and y1 <= fb
+        sent = np.concatenate([multigpu.part_row_indices(rows, n, p)[a:b] for p in range(n)])
+        assert set(range(y0, y1)) <= set(sent.tolist())
+        assert all(fa <= r < fb for r in sent.tolist())  # nothing lands in rows rank 0 has filled with sky
+    assert multigpu.message_window(100, 4, (50, 50)) == (0, 0, 0, 0)
+    assert multigpu.message_window(100, 4, None) == (0, multigpu.max_part_rows(100, 4), 0, 100)
 
 
 def test_partition_is_a_partition():

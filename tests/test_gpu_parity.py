@@ -123,6 +123,77 @@ def test_interleaved_parts_reassemble(gpu_ctx, default_scene):
         assert sum(c.rays for c in parts) == gpu_ctx.count_rays(f).rays
 
 
+_EXTENT_CAMERAS = [
+    ("default", None),
+    ("looking away", ((0.0, 0.0, 10.0), (0.0, 0.0, 20.0))),
+    ("eye inside the diorama", ((0.2, 1.0, 0.3), (3.0, 0.0, -3.0))),
+    ("far away", ((0.0, 5.0, 200.0), (0.0, 0.0, 0.0))),
+    ("scene below the frame", ((0.0, 0.0, 40.0), (0.0, 120.0, 0.0))),
+    ("from above", ((0.0, 30.0, 0.01), (0.0, 0.0, 0.0))),
+    ("NaN basis", ((0.0, 0.0, 10.0), (0.0, 0.0, 10.0))),
+]
+
+
+@pytest.mark.parametrize("name,cam", _EXTENT_CAMERAS)
+def test_row_extent_bounds_the_geometry(gpu_ctx, default_scene, name, cam):
+    """rt_frame_row_extent: rows outside the extent are sky in the rendered frame (the unpainted pixel
+    aside), for whole frames and bands; the bound is tight enough to be useful for the default view."""
+    gpu_ctx.upload(default_scene)
+    w, h = 320, 200
+    for y0, y1 in ((0, h), (37, 150), (120, 121)):
+        f = default_scene.frame(w, h, y0=y0, y1=y1, camera=_cam(*cam) if cam else None)
+        a, b = gpu_ctx.row_extent(f)
+        assert y0 <= a <= b <= y1
+        fb = gpu_ctx.render(f)
+        outside = np.concatenate([fb[: a - y0], fb[b - y0:]]).copy().reshape(-1, w)
+        expect = np.full_like(outside, f.sky_0rgb)
+        rows_out = list(range(y0, a)) + list(range(b, y1))
+        if 1 in rows_out:
+            expect[rows_out.index(1), 0] = 0
+        assert np.array_equal(outside, expect), (name, y0, y1, a, b)
+        if name == "default" and (y0, y1) == (0, h):
+            hit_rows = np.where((fb != f.sky_0rgb).any(axis=1))[0]
+            assert a >= hit_rows.min() - 8 and b <= hit_rows.max() + 8 and (b - a) < 0.6 * h
+        if name in ("looking away", "eye inside the diorama", "NaN basis"):
+            assert (a, b) == (y0, y1)  # corners behind the eye / no basis: no conclusion
+        if name == "scene below the frame":
+            assert a == b
+
+
+def test_row_extent_with_spheres_is_the_whole_band(gpu_ctx):
+    s = rt.synthetic_scene(n_cubes=50, n_spheres=3)
+    gpu_ctx.upload(s)
+    assert gpu_ctx.row_extent(s.frame(64, 48, y0=5, y1=40)) == (5, 40)
+
+
+def test_frame_pipeline_on_one_gpu(gpu_ctx, default_scene):
+    """FramePipeline (double-buffered messages, gather stream, extent-only scatter) over an orbiting camera
+    == direct renders; world 1, so the collective is absent but buffers, events and fills are the real ones."""
+    import torch
+    from raytracing_amd import multigpu
+    gpu_ctx.upload(default_scene)
+    w, h = 328, 200
+    dev = torch.device("cuda", 0)
+    ext = torch.cuda.ExternalStream(gpu_ctx.stream(), device=dev)
+    with torch.cuda.stream(ext):
+        fg = multigpu.FrameGather(h, w, 1, 0, dev, depth=2)
+    f = default_scene.frame(w, h)
+    pipe = multigpu.FramePipeline(fg, lambda buf: gpu_ctx.render_device(f, buf.data_ptr()), ext)
+    cams, got = [], []
+    cam = default_scene.camera
+    for i in range(7):
+        cam = rt.rotate_cam(cam, 0.3, 0.17 if i < 4 else -0.4)
+        f.camera = cam
+        cams.append(cam)
+        pipe.submit(gpu_ctx.row_extent(f), f.sky_0rgb)
+        if i in (2, 6):  # reading the frame needs a drain; in between, frames overlap
+            pipe.drain()
+            got.append((i, fg.frame.cpu().numpy().view(np.uint32).copy()))
+    for i, img in got:
+        f.camera = cams[i]
+        assert np.array_equal(img, gpu_ctx.render(f)), i
+
+
 def test_host_mirror_render_path(default_scene, gpu_ctx):
     """raytracer::render(framebuffer, model) of the C++ host mirror == direct C-ABI calls."""
     import ctypes as C
