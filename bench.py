@@ -135,15 +135,24 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (there is no CPU rendering path)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal of the N-GPU path on a box with one GPU: RTX950_BENCH_BACKEND=gloo RTX950_BENCH_DEVICE=0 puts
+    # every rank on the same card and moves the messages through host memory (RCCL refuses two ranks on
+    # one device).  Not a measurement.
+    backend = os.environ.get("RTX950_BENCH_BACKEND", "nccl")
+    device_index = int(os.environ.get("RTX950_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the small bookkeeping collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     kind, kwargs, W, H = WORKLOADS[args.workload]
     scene = make_scene(rt, kind, kwargs)
-    ctx = rt.Context(local_rank)
+    ctx = rt.Context(device_index)
     ctx.upload(scene)
     frame = scene.frame(W, H)
     n_lights = len(scene.lights)
@@ -196,10 +205,10 @@ def main():
     kern_ms, kern_n = ctx.kernel_time_ms()
     ctx.enable_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        km = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        km = torch.tensor([kern_ms], dtype=torch.float64, device=cdev)
         km_list = [torch.zeros_like(km) for _ in range(world)]
         dist.all_gather(km_list, km)
         kern_all = [float(x.item()) for x in km_list]
@@ -211,6 +220,17 @@ def main():
     if rank == 0:
         if orbit:
             frame.camera = scene.camera
+        if pipe is not None:
+            # the gathered frame against one rendered whole on this GPU (same camera: the last step's)
+            pipe.drain()
+            whole = torch.zeros((H, W), dtype=torch.int32, device=dev)
+            ctx.render_device(frame if not orbit else scene.frame(W, H, camera=state["cam"]), whole.data_ptr())
+            ctx.sync()
+            torch.cuda.synchronize(dev)
+            if not torch.equal(whole, fg.frame):
+                bad = int((whole != fg.frame).sum().item())
+                print(f"bench.py: the frame gathered from {world} rank(s) differs from the single-GPU frame in {bad} pixels", file=sys.stderr)
+                sys.exit(3)
         total = ctx.count_rays(frame)
         mine = ctx.count_rays(frame, n_parts=world, part=0) if world > 1 else total
         rays_uniq, rays_ref = total.rays, total.ref_rays
@@ -232,7 +252,7 @@ def main():
             "data": "reference default diorama (platform materials pinned by PCG32 0xC0FFEE, reference textures baked to RGB8)"
                     if kind == "default" else "synthetic voxel world, PCG32 0x5EED5EED",
             "config": {
-                "workload": args.workload, "width": W, "height": H, "n_cubes": scene.n_cubes, "n_spheres": scene.n_spheres,
+                "workload": args.workload, **({"rehearsal": f"backend {backend}, every rank on cuda:{device_index}: not a measurement"} if backend != "nccl" else {}), "width": W, "height": H, "n_cubes": scene.n_cubes, "n_spheres": scene.n_spheres,
                 "n_lights": n_lights, "max_depth": 3,
                 "partition": f"16-row blocks round-robin over {world} GPU(s); rows that can hold geometry gathered to GPU0 (RCCL), pipelined one frame deep" if world > 1
                              else "whole frame on one GPU",
@@ -253,6 +273,8 @@ def main():
                 "note": "algorithmic FP32 ops of the reference's brute-force walk: 26/ray-cube test + 25/ray-sphere test + 60*lights/shaded hit (SURVEY 8d), rank 0's launch; the kernel proves most tests fail without executing them, so frac can exceed 1 (executed view: valu_busy_frac_pmc)",
             },
         }
+        if pipe is not None:
+            result["config"]["frame_check"] = "gathered frame identical to the frame rendered whole on GPU0 (checked after the timed region)"
         if world == 1 and args.cpu_seconds > 0:
             cb = cpu_baseline(scene, W, H, args.cpu_seconds, args.cpu_threads)
             result["cpu_baseline"] = cb

@@ -69,6 +69,8 @@ class FrameGather:
         self.local = self.locals[0]
         self.unpainted = unpainted if (unpainted is not None and unpainted[0] < rows and unpainted[1] < width) else None
         self.frame = None
+        # gloo moves host memory only: with device buffers (rehearsals of the N-GPU path on one GPU) stage through the host
+        self._host_staging = world > 1 and torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
         self._plans = {}
         self._filled = None  # (fa, fb, sky): rows outside [fa, fb) hold this sky colour already
         if rank == 0:
@@ -107,7 +109,7 @@ class FrameGather:
         local = self.locals[slot]
         if self.rank != 0:
             if b > a:
-                dist.gather(local[a:b], None, dst=0, group=self.group)
+                dist.gather(local[a:b].cpu() if self._host_staging else local[a:b], None, dst=0, group=self.group)
             return None
         if (fa, fb) != (0, self.rows):
             if self._filled != (fa, fb, sky):
@@ -121,7 +123,13 @@ class FrameGather:
         if b > a:
             index, views, flat = self._plan(a, b)
             if self.world > 1:
-                dist.gather(local[a:b], views, dst=0, group=self.group)
+                if self._host_staging:
+                    mine = local[a:b].cpu()
+                    parts = [torch.empty_like(mine) for _ in range(self.world)]
+                    dist.gather(mine, parts, dst=0, group=self.group)
+                    flat.copy_(torch.cat(parts))
+                else:
+                    dist.gather(local[a:b], views, dst=0, group=self.group)
                 self._frame_buf.index_copy_(0, index, flat)
             else:
                 self._frame_buf.index_copy_(0, index, local[a:b])
