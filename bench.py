@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--workload", default="minecraft_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU baseline sample; 0 disables it")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="frames in flight per GPU (one library context and stream each); 0 = 1 at N=1 (launches do not overlap: "
+                         "the roofline's kernel time is a kernel alone on the GPU), 2 at N>1")
     ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
     args = ap.parse_args()
 
@@ -161,12 +164,23 @@ def main():
     # the library's own stream as a torch stream: the gather of a frame is ordered after its render by events
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
     with torch.cuda.stream(ext):
-        piped = world > 1 or bool(os.environ.get("RTX950_BENCH_PIPELINE"))  # the variable: N>1 plumbing on one GPU, for testing
-        fg = FrameGather(H, W, world, rank, dev, depth=2 if piped else 1)
+        inflight = args.inflight if args.inflight > 0 else (2 if world > 1 else 1)
+        piped = world > 1 or inflight > 1
+        fg = FrameGather(H, W, world, rank, dev, depth=inflight)
     out = fg.local  # [max_part_rows, W] int32, padded so every rank sends the same size
-    # N > 1: frame f+1 renders while frame f is gathered to GPU0 (two message buffers, gather stream);
-    # every frame is whole on GPU0 before the timed region ends (sync() below waits for all streams)
-    pipe = FramePipeline(fg, lambda buf: ctx.render_device(frame, buf.data_ptr(), n_parts=world, part=rank), ext) if piped else None
+    # N > 1: frame f+1 renders while frame f is gathered to GPU0 and while f's slowest tiles finish (a rank
+    # holds 1/N of the work but the whole critical path); every frame is whole on GPU0 before the timed
+    # region ends (sync() below waits for all streams).  2 in flight by default: with RCCL's own stream and
+    # the null stream that is one hardware queue per stream (GPU_MAX_HW_QUEUES = 4)
+    # and so does its slowest tile: one library context (own stream, queue, tile costs) per message buffer
+    ctxs, streams = [ctx], [ext]
+    if piped:
+        for _ in range(len(fg.locals) - 1):
+            c2 = rt.Context(device_index)
+            c2.upload(scene)
+            ctxs.append(c2)
+            streams.append(torch.cuda.ExternalStream(c2.stream(), device=dev))
+    pipe = FramePipeline(fg, lambda buf, slot: ctxs[slot].render_device(frame, buf.data_ptr(), n_parts=world, part=rank), streams) if piped else None
 
     orbit = bool(kwargs.get("orbit"))
     state = {"cam": scene.camera}
@@ -183,14 +197,16 @@ def main():
             pipe.submit(ctx.row_extent(frame), frame.sky_0rgb)
 
     def sync():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
     sync()
-    ctx.enable_timing(True)
-    ctx.kernel_time_ms()  # drop anything recorded so far
+    for c in ctxs:
+        c.enable_timing(True)
+        c.kernel_time_ms()  # drop anything recorded so far
     if world > 1:
         dist.barrier()
     sync()
@@ -202,8 +218,11 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = ctx.kernel_time_ms()
-    ctx.enable_timing(False)
+    kt = [c.kernel_time_ms() for c in ctxs]
+    kern_n = sum(n for _, n in kt)
+    kern_ms = sum(ms * n for ms, n in kt) / kern_n if kern_n else 0.0  # with frames in flight on two streams, launches overlap and each takes longer
+    for c in ctxs:
+        c.enable_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -254,17 +273,17 @@ def main():
             "config": {
                 "workload": args.workload, **({"rehearsal": f"backend {backend}, every rank on cuda:{device_index}: not a measurement"} if backend != "nccl" else {}), "width": W, "height": H, "n_cubes": scene.n_cubes, "n_spheres": scene.n_spheres,
                 "n_lights": n_lights, "max_depth": 3,
-                "partition": f"16-row blocks round-robin over {world} GPU(s); rows that can hold geometry gathered to GPU0 (RCCL), pipelined one frame deep" if world > 1
-                             else "whole frame on one GPU",
+                "partition": f"16-row blocks round-robin over {world} GPU(s); rows that can hold geometry gathered to GPU0 (RCCL), {inflight} frames in flight per GPU" if world > 1
+                             else ("whole frame on one GPU" + (f", {inflight} frames in flight" if inflight > 1 else "")),
                 "rays_per_frame_unique": rays_uniq, "rays_per_frame_reference": rays_ref,
                 "mrays_per_s_reference_accounting": rays_ref * args.steps / elapsed / 1e6,
                 "cube_tests_per_frame": int(total.cube_tests), "sphere_tests_per_frame": int(total.sphere_tests),
-                "kernel_ms_per_rank": kern_all,
+                "kernel_ms_per_rank": kern_all, "frames_in_flight": inflight,
             },
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic_from_profile(args.workload),
-                "kernel": "render_kernel<false,false>", "kernel_avg_ms": kern_ms, "launches_timed": kern_n,
+                "kernel": "render_kernel<false,false>", "kernel_avg_ms": kern_ms, "launches_timed": kern_n, "launches_overlap": inflight > 1,
                 "algorithmic_flops_per_launch": flops_launch,
                 "frac_of_nonfma_lane_op_ceiling": achieved_tf / PEAK_LANE_OPS_T,
                 # executed view from the committed rocprofv3 PMC pass of this command (profiles/traffic.json)
@@ -302,7 +321,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -35,14 +35,15 @@ def max_part_rows(rows, n_parts, block=ROW_BLOCK):
     return max(part_rows(rows, n_parts, p, block) for p in range(n_parts))
 
 
-def message_window(rows, n_parts, extent, block=ROW_BLOCK):
+def message_window(rows, n_parts, extent, block=ROW_BLOCK, max_rows=None):
     """Rows [a, b) of every rank's compact buffer that must travel so that all frame rows of
     `extent` = (y_first, y_end) reach rank 0, and the frame rows [fa, fb) those messages cover.
 
     Compact block k of rank p is frame block k * n_parts + p, so frame blocks [B0, B1) need compact
     blocks floor(B0 / n) .. ceil(B1 / n) - 1 on some rank; the window is the same on every rank (equal
     message sizes).  An empty extent gives an empty window: no message at all."""
-    max_rows = max_part_rows(rows, n_parts, block)
+    if max_rows is None:
+        max_rows = max_part_rows(rows, n_parts, block)
     if extent is None:
         return 0, max_rows, 0, rows
     y_first, y_end = max(0, int(extent[0])), min(rows, int(extent[1]))
@@ -58,7 +59,8 @@ class FrameGather:
     """Gathers the ranks' compact bands to rank 0 and reassembles the frame there.
 
     Every rank owns `depth` message buffers `locals[slot]`, [max_part_rows, width] int32 (padded so all
-    messages have the same size); rank 0 owns the [rows, width] frame.  `unpainted` is the
+    messages have the same size); rank 0 owns a [rows, width] frame and a receive buffer per slot
+    (`frames[slot]`, a swap chain: frames in flight never share memory).  `unpainted` is the
     band-relative (row, column) of the reference's never-painted pixel i == width (render.rs:316-322),
     or None when the band does not hold it: it matters only when rank 0 fills that row itself."""
 
@@ -68,60 +70,73 @@ class FrameGather:
         self.locals = [torch.zeros((self.max_rows, width), dtype=torch.int32, device=device) for _ in range(depth)]
         self.local = self.locals[0]
         self.unpainted = unpainted if (unpainted is not None and unpainted[0] < rows and unpainted[1] < width) else None
-        self.frame = None
+        self.frames = None
+        self.frame = None  # rank 0: the frame of the latest gather() call
         # gloo moves host memory only: with device buffers (rehearsals of the N-GPU path on one GPU) stage through the host
         self._host_staging = world > 1 and torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
         self._plans = {}
-        self._filled = None  # (fa, fb, sky): rows outside [fa, fb) hold this sky colour already
+        self._windows = {}
+        self._filled = [None] * depth  # per slot (fa, fb, sky): rows outside [fa, fb) hold this sky colour already
         if rank == 0:
             # one spare row takes the padding rows of the messages, so the scatter is ONE index_copy_
-            self._frame_buf = torch.zeros((rows + 1, width), dtype=torch.int32, device=device)
-            self.frame = self._frame_buf[:rows]
-            self._recv_flat = torch.zeros(world * self.max_rows * width, dtype=torch.int32, device=device) if world > 1 else None
+            self._frame_bufs = [torch.zeros((rows + 1, width), dtype=torch.int32, device=device) for _ in range(depth)]
+            self.frames = [b[:rows] for b in self._frame_bufs]
+            self.frame = self.frames[0]
+            self._recv_flat = [torch.zeros(world * self.max_rows * width, dtype=torch.int32, device=device) if world > 1 else None
+                               for _ in range(depth)]
             pad = np.full((world, self.max_rows), rows, dtype=np.int64)
             for p in range(world):
                 idx = part_row_indices(rows, world, p)
                 pad[p, : idx.size] = idx
             self._index_pad = pad
 
-    def _plan(self, a, b):
-        """Receive views and scatter index for the message window [a, b) (cached per window)."""
-        plan = self._plans.get((a, b))
+    def _plan(self, slot, a, b):
+        """Receive views and scatter index for the message window [a, b) of a slot (cached)."""
+        plan = self._plans.get((slot, a, b))
         if plan is None:
             m = b - a
-            index = torch.from_numpy(np.ascontiguousarray(self._index_pad[:, a:b]).reshape(-1)).to(self._frame_buf.device)
+            index = self._plans.get(("index", a, b))
+            if index is None:
+                index = torch.from_numpy(np.ascontiguousarray(self._index_pad[:, a:b]).reshape(-1)).to(self._frame_bufs[0].device)
+                self._plans[("index", a, b)] = index
             if self.world > 1:
-                block = self._recv_flat[: self.world * m * self.width].view(self.world, m, self.width)
+                block = self._recv_flat[slot][: self.world * m * self.width].view(self.world, m, self.width)
                 plan = (index, [block[p] for p in range(self.world)], block.view(self.world * m, self.width))
             else:
                 plan = (index, None, None)
-            self._plans[(a, b)] = plan
+            self._plans[(slot, a, b)] = plan
         return plan
 
     def gather(self, slot=0, extent=None, sky=None):
-        """Collective: after it returns (stream-ordered), rank 0's `frame` holds the whole frame.
+        """Collective: after it returns (stream-ordered), rank 0's `frames[slot]` (= `frame`) holds the
+        whole frame.
 
         extent = (y_first, y_end) from rt_frame_row_extent and sky = the frame's sky colour: rows outside
         the extent are not sent, rank 0 paints them.  Every rank must pass the same extent."""
         if extent is not None and sky is None:
             raise ValueError("an extent needs the sky colour for the rows that are not sent")
-        a, b, fa, fb = message_window(self.rows, self.world, extent)
+        key = None if extent is None else (int(extent[0]), int(extent[1]))
+        win = self._windows.get(key)
+        if win is None:  # per-frame host work is a dictionary look-up
+            win = self._windows[key] = message_window(self.rows, self.world, key, max_rows=self.max_rows)
+        a, b, fa, fb = win
         local = self.locals[slot]
         if self.rank != 0:
             if b > a:
                 dist.gather(local[a:b].cpu() if self._host_staging else local[a:b], None, dst=0, group=self.group)
             return None
+        buf = self._frame_bufs[slot]
         if (fa, fb) != (0, self.rows):
-            if self._filled != (fa, fb, sky):
-                self._frame_buf[:fa].fill_(sky)
-                self._frame_buf[fb : self.rows].fill_(sky)
+            if self._filled[slot] != (fa, fb, sky):
+                buf[:fa].fill_(sky)
+                buf[fb : self.rows].fill_(sky)
                 if self.unpainted is not None and not (fa <= self.unpainted[0] < fb):
-                    self._frame_buf[self.unpainted[0], self.unpainted[1]] = 0
-                self._filled = (fa, fb, sky)
+                    buf[self.unpainted[0], self.unpainted[1]] = 0
+                self._filled[slot] = (fa, fb, sky)
         else:
-            self._filled = None
+            self._filled[slot] = None
         if b > a:
-            index, views, flat = self._plan(a, b)
+            index, views, flat = self._plan(slot, a, b)
             if self.world > 1:
                 if self._host_staging:
                     mine = local[a:b].cpu()
@@ -130,48 +145,54 @@ class FrameGather:
                     flat.copy_(torch.cat(parts))
                 else:
                     dist.gather(local[a:b], views, dst=0, group=self.group)
-                self._frame_buf.index_copy_(0, index, flat)
+                buf.index_copy_(0, index, flat)
             else:
-                self._frame_buf.index_copy_(0, index, local[a:b])
+                buf.index_copy_(0, index, local[a:b])
+        self.frame = self.frames[slot]
         return self.frame
 
 
 class FramePipeline:
-    """Renders frame f+1 while frame f is gathered: message buffers alternate, the gather (and rank 0's
-    fill and scatter) run on their own stream, events order buffer reuse.
+    """Keeps `depth` frames in flight per rank: frame f+1 renders while frame f is gathered - and while
+    frame f's slowest tiles are still being traced.  A rank of an N-GPU job holds 1/N of the frame's
+    work but all of its critical path (the slowest 8x8 tile takes 80 % of the whole frame's kernel time
+    by itself), so one frame in flight leaves its GPU idle most of the time.
 
-    render(buffer) enqueues this rank's part of the next frame on `render_stream` (a torch stream
-    wrapping the library's: torch.cuda.ExternalStream(ctx.stream())).  On a CPU device (gloo tests)
-    everything runs in program order."""
+    Slot s = f mod depth owns a message buffer, a library context with its stream, and on rank 0 a
+    receive buffer and a frame (FrameGather.frames[s]).  Everything of a frame - render, collective,
+    rank 0's fill and scatter - is enqueued on its slot's stream, in that order, so a slot needs no
+    events: its next frame queues up behind; different slots overlap.  (RCCL runs the collective on its
+    own stream, fenced both ways against the stream it is called on, and executes collectives in call
+    order, which is the same on every rank.)
 
-    def __init__(self, gather: FrameGather, render, render_stream=None):
-        self.g, self.render, self.render_stream = gather, render, render_stream
+    render(buffer, slot) enqueues this rank's part of the next frame on render_streams[slot] (torch
+    streams wrapping the library's: torch.cuda.ExternalStream(ctx.stream())).  On a CPU device (gloo
+    tests, render_streams=None) everything runs in program order."""
+
+    def __init__(self, gather: FrameGather, render, render_streams=None):
+        self.g, self.render = gather, render
         self.depth = len(gather.locals)
         self.n = 0
-        self.cuda = render_stream is not None
+        self.cuda = render_streams is not None
         if self.cuda:
-            dev = render_stream.device
-            self.comm_stream = torch.cuda.Stream(device=dev)
-            self.rendered = [torch.cuda.Event() for _ in range(self.depth)]
-            self.gathered = [torch.cuda.Event() for _ in range(self.depth)]
+            if len(render_streams) != self.depth or len(set(s.cuda_stream for s in render_streams)) != self.depth:
+                raise ValueError("one render stream per message buffer")
+            self.render_streams = list(render_streams)
 
     def submit(self, extent=None, sky=None):
+        """Returns the slot: on rank 0 the frame will be FrameGather.frames[slot]."""
         slot = self.n % self.depth
-        if self.cuda and self.n >= self.depth:
-            self.render_stream.wait_event(self.gathered[slot])  # the buffer's previous message has left
-        self.render(self.g.locals[slot])
+        self.render(self.g.locals[slot], slot)
         if self.cuda:
-            self.rendered[slot].record(self.render_stream)
-            self.comm_stream.wait_event(self.rendered[slot])
-            with torch.cuda.stream(self.comm_stream):
+            with torch.cuda.stream(self.render_streams[slot]):
                 self.g.gather(slot, extent, sky)
-                self.gathered[slot].record(self.comm_stream)
         else:
             self.g.gather(slot, extent, sky)
         self.n += 1
+        return slot
 
     def drain(self):
-        """Host wait until every submitted frame has reached rank 0's frame."""
+        """Host wait until every submitted frame has reached rank 0."""
         if self.cuda:
-            self.comm_stream.synchronize()
-            self.render_stream.synchronize()
+            for rs in self.render_streams:
+                rs.synchronize()

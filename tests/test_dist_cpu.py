@@ -73,7 +73,7 @@ def _pipeline_worker(rank, world, port, rows, width, out_path):
     idx = multigpu.part_row_indices(rows, world, rank)
     state = {}
 
-    def render(buf):
+    def render(buf, slot):
         buf.fill_(-1)  # rows past the part stay garbage: they must never reach the frame
         buf[: len(idx)] = torch.from_numpy(_image(rows, width, state["extent"], state["tag"])[idx])
 

@@ -178,7 +178,12 @@ def test_frame_pipeline_on_one_gpu(gpu_ctx, default_scene):
     with torch.cuda.stream(ext):
         fg = multigpu.FrameGather(h, w, 1, 0, dev, depth=2)
     f = default_scene.frame(w, h)
-    pipe = multigpu.FramePipeline(fg, lambda buf: gpu_ctx.render_device(f, buf.data_ptr()), ext)
+    # one context (and stream) per message buffer, as bench.py does for N > 1
+    ctx2 = rt.Context(0)
+    ctx2.upload(default_scene)
+    ctxs = [gpu_ctx, ctx2]
+    streams = [ext, torch.cuda.ExternalStream(ctx2.stream(), device=dev)]
+    pipe = multigpu.FramePipeline(fg, lambda buf, slot: ctxs[slot].render_device(f, buf.data_ptr()), streams)
     cams, got = [], []
     cam = default_scene.camera
     for i in range(7):
@@ -192,6 +197,7 @@ def test_frame_pipeline_on_one_gpu(gpu_ctx, default_scene):
     for i, img in got:
         f.camera = cams[i]
         assert np.array_equal(img, gpu_ctx.render(f)), i
+    ctx2.close()
 
 
 def test_host_mirror_render_path(default_scene, gpu_ctx):
