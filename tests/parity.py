@@ -29,3 +29,31 @@ def assert_parity(gpu_fb, gpu_planes, ref_fb, ref_planes, label=""):
     rep = colour_report(gpu_fb, ref_fb)
     assert rep["within_1lsb_fraction"] >= COLOUR_MIN_FRACTION, f"{label}: colour parity {rep}"
     return rep
+
+
+def random_scene(rt, base_scene, seed, max_cubes=None):
+    """Fuzz scene of tests/test_gpu_parity.py::test_random_scenes and tools/fuzz_soak.py: random cubes
+    (touching, overlapping, repeated ids, on a lattice so that rays hit edges and shared faces),
+    spheres, materials with random reflectivity/transparency/index, lights and a camera."""
+    rng = np.random.default_rng(1000 + seed)
+    V = rt.Vec3
+    base = list(base_scene.materials)
+    mats = []
+    for k in range(6):
+        m = rt.Material.from_buffer_copy(base[int(rng.integers(len(base)))])
+        m.reflectivity = float(rng.choice([0.0, 0.0, 0.25, 0.5, 1.0]))
+        m.transparency = float(rng.choice([0.0, 0.0, 0.3, 0.75]))
+        m.refractive_index = float(rng.choice([1.0, 1.33, 1.5, 0.5]))
+        m.specular = float(rng.choice([0.0, 1.0, 2.0, 10.0, 50.0, 125.0]))
+        mats.append(m)
+    n_c = int(rng.integers(1, (400 if seed % 3 == 0 else 60) if max_cubes is None else max_cubes))
+    cubes = [rt.Cube(int(rng.integers(0, 8)), V(*(rng.integers(-6, 7, 3) * 0.75).tolist()), float(rng.choice([0.75, 1.5, 1.5, 3.0])), int(rng.integers(len(mats))))
+             for _ in range(n_c)]
+    spheres = [rt.Sphere(100 + k, V(*(rng.uniform(-6, 6, 3)).tolist()), float(rng.uniform(0.2, 2.0)), int(rng.integers(len(mats))))
+               for k in range(int(rng.integers(0, 5)))]
+    lights = [rt.Light(V(*(rng.uniform(-12, 12, 3)).tolist()), int(rng.integers(0, 1 << 24)), float(rng.uniform(0.1, 1.5)))
+              for _ in range(int(rng.integers(1, 4)))]
+    eye = rng.uniform(-14, 14, 3)
+    cam = rt.Camera(V(*eye.tolist()), V(*rng.uniform(-2, 2, 3).tolist()), V(0.0, 1.0, 0.0))
+    sc = rt.make_scene(cubes, spheres, mats, lights, cam, float(rng.uniform(0.0, 0.5)), int(rng.integers(0, 1 << 24)), base_scene.atlas)
+    return sc, f"random scene {seed} ({n_c} cubes, {len(spheres)} spheres, {len(lights)} lights)"

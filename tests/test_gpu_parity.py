@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import raytracing_amd as rt
-from parity import assert_parity, colour_report
+from parity import assert_parity, colour_report, random_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -361,30 +361,8 @@ def test_degenerate_spheres(gpu_ctx, oracle_mod, default_scene):
 
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_random_scenes(gpu_ctx, oracle_mod, default_scene, seed):
-    """Fuzz: random cubes (touching, overlapping, repeated ids, on a lattice so that rays hit edges and
-    shared faces), spheres, materials with random reflectivity/transparency/index, lights and cameras."""
-    rng = np.random.default_rng(1000 + seed)
-    s = default_scene
-    V = rt.Vec3
-    base = list(s.materials)
-    mats = []
-    for k in range(6):
-        m = rt.Material.from_buffer_copy(base[int(rng.integers(len(base)))])
-        m.reflectivity = float(rng.choice([0.0, 0.0, 0.25, 0.5, 1.0]))
-        m.transparency = float(rng.choice([0.0, 0.0, 0.3, 0.75]))
-        m.refractive_index = float(rng.choice([1.0, 1.33, 1.5, 0.5]))
-        m.specular = float(rng.choice([0.0, 1.0, 2.0, 10.0, 50.0, 125.0]))
-        mats.append(m)
-    n_c = int(rng.integers(1, 400 if seed % 3 == 0 else 60))
-    cubes = [rt.Cube(int(rng.integers(0, 8)), V(*(rng.integers(-6, 7, 3) * 0.75).tolist()), float(rng.choice([0.75, 1.5, 1.5, 3.0])), int(rng.integers(len(mats))))
-             for _ in range(n_c)]
-    spheres = [rt.Sphere(100 + k, V(*(rng.uniform(-6, 6, 3)).tolist()), float(rng.uniform(0.2, 2.0)), int(rng.integers(len(mats))))
-               for k in range(int(rng.integers(0, 5)))]
-    lights = [rt.Light(V(*(rng.uniform(-12, 12, 3)).tolist()), int(rng.integers(0, 1 << 24)), float(rng.uniform(0.1, 1.5)))
-              for _ in range(int(rng.integers(1, 4)))]
-    eye = rng.uniform(-14, 14, 3)
-    cam = _cam(tuple(eye.tolist()), tuple(rng.uniform(-2, 2, 3).tolist()))
-    sc = rt.make_scene(cubes, spheres, mats, lights, cam, float(rng.uniform(0.0, 0.5)), int(rng.integers(0, 1 << 24)), s.atlas)
+    """Fuzz (parity.random_scene); tools/fuzz_soak.py runs the same generator over hundreds of seeds."""
+    sc, label = random_scene(rt, default_scene, seed)
     f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, 96, 64)
-    assert_parity(gfb, gpl, ofb, opl, f"random scene {seed} ({n_c} cubes, {len(spheres)} spheres, {len(lights)} lights)")
+    assert_parity(gfb, gpl, ofb, opl, label)
     assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
