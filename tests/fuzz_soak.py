@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_soak.py [first_seed] [n_seeds] [max_cubes]: the fuzz of tests/test_gpu_parity.py::test_random_scenes
+"""tests/fuzz_soak.py [first_seed] [n_seeds] [max_cubes]: the fuzz of tests/test_gpu_parity.py::test_random_scenes
 over many seeds (GPU through the C-ABI against the oracle: hit planes and ray-tree hashes bit-exact, colour
 within 1 LSB on >= 99.9 % of pixels, ray counters equal).  Prints one line per failing seed and a summary."""
 import os

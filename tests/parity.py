@@ -32,7 +32,7 @@ def assert_parity(gpu_fb, gpu_planes, ref_fb, ref_planes, label=""):
 
 
 def random_scene(rt, base_scene, seed, max_cubes=None):
-    """Fuzz scene of tests/test_gpu_parity.py::test_random_scenes and tools/fuzz_soak.py: random cubes
+    """Fuzz scene of tests/test_gpu_parity.py::test_random_scenes and tests/fuzz_soak.py: random cubes
     (touching, overlapping, repeated ids, on a lattice so that rays hit edges and shared faces),
     spheres, materials with random reflectivity/transparency/index, lights and a camera."""
     rng = np.random.default_rng(1000 + seed)

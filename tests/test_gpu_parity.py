@@ -84,7 +84,7 @@ def test_night_and_orbit_match_oracle(gpu_ctx, oracle_mod, default_scene):
 
 
 def test_golden_fixtures(gpu_ctx):
-    """GPU vs the committed oracle outputs (tests/golden/*.npz, made by tools/make_golden.py)."""
+    """GPU vs the committed oracle outputs (tests/golden/*.npz, made by tests/make_golden.py)."""
     import os
     gdir = os.path.join(os.path.dirname(__file__), "golden")
     cases = [("minecraft_270x180.npz", rt.default_scene(), 270, 180),
@@ -361,7 +361,7 @@ def test_degenerate_spheres(gpu_ctx, oracle_mod, default_scene):
 
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_random_scenes(gpu_ctx, oracle_mod, default_scene, seed):
-    """Fuzz (parity.random_scene); tools/fuzz_soak.py runs the same generator over hundreds of seeds."""
+    """Fuzz (parity.random_scene); tests/fuzz_soak.py runs the same generator over hundreds of seeds."""
     sc, label = random_scene(rt, default_scene, seed)
     f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, 96, 64)
     assert_parity(gfb, gpl, ofb, opl, label)

@@ -158,7 +158,7 @@ def test_numpy_restatement_agrees_on_hit_indices(oracle_mod, default_scene):
 
 
 def test_golden_frame(oracle_mod, default_scene):
-    """tests/golden/minecraft_270x180.npz was produced by tools/make_golden.py from this oracle; it pins the
+    """tests/golden/minecraft_270x180.npz was produced by tests/make_golden.py from this oracle; it pins the
     oracle against accidental change and gives the GPU tests a fixture that needs no oracle run."""
     g = np.load(os.path.join(GOLDEN, "minecraft_270x180.npz"))
     fb, planes, cnt, _ = oracle_mod.OracleScene(default_scene).render(default_scene.frame(270, 180), debug=True, reuse_secondary=True)
