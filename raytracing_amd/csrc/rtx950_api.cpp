@@ -38,6 +38,9 @@ struct rt_ctx {
     float* d_sphere_filt = nullptr;
     uint32_t* d_bvh_items = nullptr;
     float* d_chunk_box = nullptr;
+    float* d_cube_filt_list = nullptr;   // list-ordered stream for shadow queries of long lists (when compact)
+    uint32_t* d_cube_id_list = nullptr;
+    float* d_chunk_box_list = nullptr;
     uint32_t* d_cube_mat = nullptr;
     SphereRec* d_spheres = nullptr;
     SphereMeta* d_sphere_meta = nullptr;
@@ -129,6 +132,12 @@ void free_scene(rt_ctx* c)
     c->d_bvh_items = nullptr;
     (void)hipFree(c->d_chunk_box);
     c->d_chunk_box = nullptr;
+    (void)hipFree(c->d_cube_filt_list);
+    c->d_cube_filt_list = nullptr;
+    (void)hipFree(c->d_cube_id_list);
+    c->d_cube_id_list = nullptr;
+    (void)hipFree(c->d_chunk_box_list);
+    c->d_chunk_box_list = nullptr;
     (void)hipFree(c->d_cube_mat);
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_sphere_meta);
@@ -506,26 +515,67 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     ctx->h_n_spheres = n_spheres;
     const size_t n_chunks = large ? (n_cubes + 63) / 64 : 0;
     const size_t n_box = ((n_chunks + 63) / 64) * 64 + 64;
-    std::vector<float> hbox(n_box * 8, 0.0f);
-    for (size_t c = 0; c < n_chunks; ++c) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        bool finite = true;
-        for (size_t j = c * 64; j < std::min(n_cubes, c * 64 + 64); ++j) {
-            const CubeRec& r = hc[perm[j]];
-            const float b[3][2] = {{r.minx, r.maxx}, {r.miny, r.maxy}, {r.minz, r.maxz}};
-            for (int k = 0; k < 3; ++k)
-                for (int e = 0; e < 2; ++e) {
-                    if (!std::isfinite(b[k][e])) finite = false;
-                    lo[k] = std::min(lo[k], (double)b[k][e]); hi[k] = std::max(hi[k], (double)b[k][e]);
-                }
+    // bounding box per chunk of 64 consecutive records of a stream given by its list indices; returns the
+    // sum of the boxes' half-extent sums (a measure of how compact the stream's chunks are)
+    auto chunk_boxes = [&](const uint32_t* order, std::vector<float>& out) {
+        double total = 0.0;
+        out.assign(n_box * 8, 0.0f);
+        for (size_t c = 0; c < n_chunks; ++c) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool finite = true;
+            for (size_t j = c * 64; j < std::min(n_cubes, c * 64 + 64); ++j) {
+                const CubeRec& r = hc[order[j]];
+                const float b[3][2] = {{r.minx, r.maxx}, {r.miny, r.maxy}, {r.minz, r.maxz}};
+                for (int k = 0; k < 3; ++k)
+                    for (int e = 0; e < 2; ++e) {
+                        if (!std::isfinite(b[k][e])) finite = false;
+                        lo[k] = std::min(lo[k], (double)b[k][e]); hi[k] = std::max(hi[k], (double)b[k][e]);
+                    }
+            }
+            for (int k = 0; k < 3; ++k) {
+                // centre rounded to f32, half extent rounded up so that centre +- half still covers [lo, hi]
+                const float ctr = finite ? (float)((lo[k] + hi[k]) * 0.5) : 0.0f;
+                float half = finite ? (float)std::max(hi[k] - (double)ctr, (double)ctr - lo[k]) : INFINITY;
+                if (finite) half = std::nextafter(half, INFINITY);
+                out[8 * c + k] = ctr;
+                out[8 * c + 4 + k] = half;
+                total += half;
+            }
+            // lowest list index in the chunk (shadow queries want the lowest index that passes)
+            uint32_t first = 0xFFFFFFFFu;
+            for (size_t j = c * 64; j < std::min(n_cubes, c * 64 + 64); ++j) first = std::min(first, order[j]);
+            std::memcpy(&out[8 * c + 3], &first, sizeof(first));
         }
-        for (int k = 0; k < 3; ++k) {
-            // centre rounded to f32, half extent rounded up so that centre +- half still covers [lo, hi]
-            const float ctr = finite ? (float)((lo[k] + hi[k]) * 0.5) : 0.0f;
-            float half = finite ? (float)std::max(hi[k] - (double)ctr, (double)ctr - lo[k]) : INFINITY;
-            if (finite) half = std::nextafter(half, INFINITY);
-            hbox[8 * c + k] = ctr;
-            hbox[8 * c + 4 + k] = half;
+        return total;
+    };
+    std::vector<float> hbox;
+    const double morton_extent = chunk_boxes(perm.data(), hbox);
+    // Shadow queries want the LOWEST list index that passes (render.rs:44-70 stops at the first), so a
+    // stream in list order lets them stop at the first chunk that answers every ray - if consecutive list
+    // entries are neighbours in space (a generated world is; a shuffled list is not), i.e. if the chunks
+    // of the list-ordered stream are not much larger than those of the Morton-ordered one.
+    std::vector<float> hf_list, hbox_list;
+    std::vector<uint32_t> hid_list;
+    bool shadow_list = false;
+    if (large) {
+        std::vector<uint32_t> ident(n_filt, 0u);
+        for (size_t i = 0; i < n_cubes; ++i) ident[i] = (uint32_t)i;
+        const double list_extent = chunk_boxes(ident.data(), hbox_list);
+        shadow_list = std::isfinite(list_extent) && std::isfinite(morton_extent) && list_extent <= 3.0 * morton_extent;
+        if (const char* e = getenv("RTX950_SHADOW_LIST")) shadow_list = atoi(e) != 0;  // tuning experiments / tests
+        if (shadow_list) {
+            hf_list.resize(n_filt * 4);
+            hid_list.assign(n_filt, 0u);
+            for (size_t j = 0; j < n_filt; ++j) {
+                hf_list[4 * j + 0] = 1e18f; hf_list[4 * j + 1] = -1e18f; hf_list[4 * j + 2] = 1e18f; hf_list[4 * j + 3] = 0.0f;
+            }
+            for (size_t j = 0; j < n_cubes; ++j) {
+                hf_list[4 * j + 0] = cubes[j].center.x; hf_list[4 * j + 1] = cubes[j].center.y; hf_list[4 * j + 2] = cubes[j].center.z;
+                hf_list[4 * j + 3] = std::fabs(cubes[j].size / 2.0f);
+                hid_list[j] = cubes[j].id;
+            }
+        } else {
+            hbox_list.clear();
         }
     }
     // BVH for incoherent bundles: items = stream records in Morton order (a long list's stream already is)
@@ -584,7 +634,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
             const size_t me = nodes.size();
             nodes.push_back(BvhNode{});
             box_of(lo_i, hi_i, nodes[me]);
-            if (hi_i - lo_i <= 4) {
+            if (hi_i - lo_i <= kBvhLeafMax) {
                 nodes[me].first_count = (uint32_t)((lo_i << 3) | (hi_i - lo_i));
             } else {
                 uint32_t min_idx = 0xFFFFFFFFu;  // lowest list index below this node (shadow pruning)
@@ -642,6 +692,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     if ((rc = upload(ctx, &ctx->d_cube_id, hid)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_cube_perm, perm)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_chunk_box, hbox)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_cube_filt_list, hf_list)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_cube_id_list, hid_list)) != RT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_chunk_box_list, hbox_list)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_bvh, nodes)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_bvh_items, items)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_spheres, hs)) != RT_OK) return rc;
@@ -658,6 +711,10 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.cube_id = ctx->d_cube_id;
     b.cube_perm = ctx->d_cube_perm;
     b.chunk_box = ctx->d_chunk_box;
+    b.cube_filt_list = ctx->d_cube_filt_list;
+    b.cube_id_list = ctx->d_cube_id_list;
+    b.chunk_box_list = ctx->d_chunk_box_list;
+    b.shadow_list = shadow_list ? 1u : 0u;
     b.n_chunks = (uint32_t)n_chunks;
     b.bvh = ctx->d_bvh;
     b.bvh_items = ctx->d_bvh_items;

@@ -62,6 +62,10 @@ struct LightRec {
 };
 
 constexpr int kMaxLights = 16;
+#ifndef RTX_BVH_LEAF_MAX
+#define RTX_BVH_LEAF_MAX 2
+#endif
+constexpr uint32_t kBvhLeafMax = RTX_BVH_LEAF_MAX;  // cubes per BVH leaf (3 count bits: at most 7; swept on the 10k-cube world: 1..3 equal, 4 +5 %, 6 +18 %)
 constexpr uint32_t kRowBlock = 16;  // rows per workgroup tile and per interleave block
 
 struct Params {
@@ -75,6 +79,12 @@ struct Params {
     // extents.xyz, -): the bounding box of the 64 cubes of a chunk
     const uint32_t* cube_perm;
     const float* chunk_box;
+    // shadow_list != 0 (long lists whose list order is spatially compact): the same stream and chunk boxes in
+    // LIST order, so that a shadow query can stop at the first chunk that answers every ray
+    const float* cube_filt_list;
+    const uint32_t* cube_id_list;
+    const float* chunk_box_list;
+    uint32_t shadow_list;
     uint32_t n_chunks;
     // every scene: cube_perm is valid (identity for short lists); bvh_items[k] = stream record of leaf item k
     const BvhNode* bvh;

@@ -545,6 +545,11 @@ DEV float dpp_f(float old, float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
                                                                  ROW_MASK, 0xf, false));
 }
+template <int CTRL, int ROW_MASK>
+DEV uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
 DEV float readlane_f(float v, uint32_t lane)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)lane));
@@ -562,6 +567,18 @@ DEV float wave_max(float v)
     v = __builtin_fmaxf(v, dpp_f<0x142, 0xa>(id, v));
     v = __builtin_fmaxf(v, dpp_f<0x143, 0xc>(id, v));
     return readlane_f(v, 63u);
+}
+
+// max over the 64 lanes of an unsigned value (same sweep with v_max_u32; identity 0)
+DEV uint32_t wave_max_u32(uint32_t v)
+{
+    v = __builtin_elementwise_max(v, dpp_u32<0x111, 0xf>(v));
+    v = __builtin_elementwise_max(v, dpp_u32<0x112, 0xf>(v));
+    v = __builtin_elementwise_max(v, dpp_u32<0x114, 0xf>(v));
+    v = __builtin_elementwise_max(v, dpp_u32<0x118, 0xf>(v));
+    v = __builtin_elementwise_max(v, dpp_u32<0x142, 0xa>(v));
+    v = __builtin_elementwise_max(v, dpp_u32<0x143, 0xc>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // ---------------------------------------------------------------- wave-cooperative cull
@@ -812,19 +829,52 @@ DEV void cube_query_large(const Params& P, const RayPre& q, const CullPre& cp, b
     PROF_KCOUNT(qk, 1);
     PROF_MARK(PH_PRE);
     const uint32_t lane = threadIdx.x & 63u;
-    const f32x4* filt = (const f32x4*)P.cube_filt;
-    const f32x4* boxes = (const f32x4*)P.chunk_box;
+    // Shadow queries of a list whose order is spatially compact walk the LIST-ordered stream: chunks and
+    // records then come in ascending list index, and the walk ends with the first chunk after which every
+    // active ray has a blocker (a later chunk only holds higher indices).
+    bool in_list_order = false;
+    if constexpr (MODE == Q_SHADOW) in_list_order = P.shadow_list != 0u;
+    const f32x4* filt = (const f32x4*)(in_list_order ? P.cube_filt_list : P.cube_filt);
+    const f32x4* boxes = (const f32x4*)(in_list_order ? P.chunk_box_list : P.chunk_box);
+    const uint32_t* id_stream = in_list_order ? P.cube_id_list : P.cube_id;
     for (uint32_t cg = 0; cg < n_chunks; cg += 64u) {
         const f32x4 bk = boxes[(size_t)(cg + lane) * 2u], bh = boxes[(size_t)(cg + lane) * 2u + 1u];  // padded to a multiple of 64 chunks
         unsigned long long CM = wave_ballot(chunk_test(bk, bh, cp) && (cg + lane < n_chunks));
+        const float bk3 = bk[3];  // scalar copy first: see the note at u2f
+        const uint32_t chunk_first = __builtin_bit_cast(uint32_t, bk3);  // lowest list index in lane's chunk
+        bool refresh = true;  // Q_SHADOW: some lane's blocker may have changed since the chunks were last screened
         while (CM != 0ull) {
+            // Chunks that cannot change any lane's result are not loaded.  Shadow: only the lowest list index
+            // counts, so a chunk whose lowest index is not below every active lane's blocker is done with.
+            // Nearest: every cube of a chunk has distance >= the chunk box's entry parameter (negative ones
+            // included), as in the BVH walk below.
+            if constexpr (MODE == Q_SHADOW) {
+                if (refresh) {
+                    const uint32_t need = wave_max_u32(active ? st.blocker : 0u);  // kNoHit while a lane has none
+                    CM &= wave_ballot(chunk_first < need);
+                    refresh = false;
+                    if (CM == 0ull) break;
+                }
+            }
             const uint32_t c = (uint32_t)__builtin_ctzll(CM);
             CM &= CM - 1ull;
+            if constexpr (MODE != Q_SHADOW) {
+                const float cx = readlane_f(bk[0], c), cy = readlane_f(bk[1], c), cz = readlane_f(bk[2], c);
+                const float hx = readlane_f(bh[0], c), hy = readlane_f(bh[1], c), hz = readlane_f(bh[2], c);
+                const float nx = __builtin_fmaf(hx, q.na_xy[0], __builtin_fmaf(cx, q.r_xy[0], q.c_xy[0]));
+                const float ny = __builtin_fmaf(hy, q.na_xy[1], __builtin_fmaf(cy, q.r_xy[1], q.c_xy[1]));
+                const float nz = __builtin_fmaf(hz, q.a_z_pm[0], __builtin_fmaf(cz, q.rc_z[0], q.rc_z[1]));
+                const float lo = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+                bool open;  // NaN and unsafe rays (tol = inf) compare false: not pruned
+                if constexpr (MODE == Q_NEAREST) open = !(lo > st.b1 + 2.0f * q.tol);
+                else open = !(lo - q.tol > st.best);
+                if (!wave_any(active && open)) continue;
+            }
             const uint32_t base = (cg + c) * 64u;
             const f32x4 rec = filt[base + lane];
-            const uint32_t perm = P.cube_perm[base + lane];
+            const uint32_t perm = in_list_order ? base + lane : P.cube_perm[base + lane];
             uint32_t ids = 0u;
-            if constexpr (MODE == Q_SHADOW) ids = P.cube_id[base + lane];
+            if constexpr (MODE == Q_SHADOW) ids = id_stream[base + lane];
             unsigned long long M = wave_ballot(cull_test(rec, cp) && (base + lane < n));
             PROF_MARK(PH_CULL);
             while (M != 0ull) {
@@ -835,6 +885,10 @@ DEV void cube_query_large(const Params& P, const RayPre& q, const CullPre& cp, b
                 uint32_t cid = 0u;
                 if constexpr (MODE == Q_SHADOW) cid = (uint32_t)__builtin_amdgcn_readlane((int)ids, (int)b);
                 cube_candidate<MODE, true>(P, q, active, any_zero, o, d, impact_id, i, cid, kx, ky, kz, kh, st PROF_PASS);
+                refresh = true;
+                if constexpr (MODE == Q_SHADOW) {
+                    if (in_list_order && !wave_any(active && !st.done)) return;  // ascending indices: nothing later can be lower
+                }
             }
             PROF_MARK(PH_CAND);
         }
@@ -853,6 +907,7 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
 {
     const bool any_zero = wave_any(active && q.zbits != 0u);
     PROF_COUNT(6, 1);
+    PROF_COUNT(2, 65536);  // profile builds: BVH walks in the high half of counter 2
     PROF_KCOUNT(qk, 1);
     PROF_MARK(PH_PRE);
     const float wxy = o.x * d.y - o.y * d.x, wyz = o.y * d.z - o.z * d.y, wzx = o.z * d.x - o.x * d.z;
@@ -898,15 +953,24 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
         const bool leaf = meet && (cnt != 0u);
         PROF_MARK(PH_CULL);
         if (wave_any(leaf)) {
-            for (uint32_t c = 0; c < 4u; ++c) {
+            // A lane's walk is a chain of dependent loads and these waves are the frame's critical path: the
+            // leaf's records are fetched together, and a long list's items are its stream records
+            // themselves (rt_scene_upload: bvh_items is the identity there), one level of indirection less.
+            f32x4 rec[kBvhLeafMax];
+            uint32_t idx[kBvhLeafMax], ids[kBvhLeafMax];
+#pragma unroll
+            for (uint32_t c = 0; c < kBvhLeafMax; ++c) {
+                const uint32_t sp = (leaf && c < cnt) ? first + c : 0u;
+                rec[c] = filt[sp];
+                idx[c] = P.cube_perm[sp];
+                ids[c] = 0u;
+                if constexpr (MODE == Q_SHADOW) ids[c] = P.cube_id[sp];
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < kBvhLeafMax; ++c) {
                 const bool lc = leaf && (c < cnt);
                 if (!wave_any(lc)) break;
-                const uint32_t sp = P.bvh_items[lc ? first + c : 0u];  // stream record of the leaf's c-th cube
-                const f32x4 rec = filt[sp];
-                const uint32_t i = P.cube_perm[sp];
-                uint32_t cid = 0u;
-                if constexpr (MODE == Q_SHADOW) cid = P.cube_id[sp];
-                cube_candidate<MODE, false>(P, q, lc, any_zero, o, d, impact_id, i, cid, rec[0], rec[1], rec[2], rec[3], st PROF_PASS);
+                cube_candidate<MODE, false>(P, q, lc, any_zero, o, d, impact_id, idx[c], ids[c], rec[c][0], rec[c][1], rec[c][2], rec[c][3], st PROF_PASS);
             }
             PROF_MARK(PH_CAND);
         }

@@ -302,16 +302,38 @@ def test_shared_reciprocal_division_is_ieee(gpu_ctx):
         assert n > (1 << 30) and bad == 0, (bad, n)
 
 
-@pytest.mark.parametrize("scale", ["0", "1e9"])
-def test_long_list_paths_forced(gpu_ctx, oracle_mod, scale, monkeypatch):
+@pytest.mark.parametrize("scale,shadow_list", [("0", "1"), ("1e9", "1"), ("1e9", "0")])
+def test_long_list_paths_forced(gpu_ctx, oracle_mod, scale, shadow_list, monkeypatch):
     """Long cube lists have two traversals (wave-cooperative over Morton-ordered chunks with chunk boxes,
     per-lane BVH walk for incoherent bundles); the choice per wave is a threshold.  Force each one for
-    every wave (RTX950_COHERENT_SCALE is read by rt_scene_upload) and require the same parity."""
+    every wave (RTX950_COHERENT_SCALE is read by rt_scene_upload) and require the same parity.  Shadow
+    queries of the cooperative traversal walk a list-ordered or the Morton-ordered stream, a choice per
+    scene (RTX950_SHADOW_LIST forces it)."""
     monkeypatch.setenv("RTX950_COHERENT_SCALE", scale)
+    monkeypatch.setenv("RTX950_SHADOW_LIST", shadow_list)
     scene = rt.synthetic_scene(n_cubes=900, n_spheres=8)
     f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, scene, 200, 120)
-    assert_parity(gfb, gpl, ofb, opl, f"synthetic 900c, coherent scale {scale}")
+    assert_parity(gfb, gpl, ofb, opl, f"synthetic 900c, coherent scale {scale}, shadow list {shadow_list}")
     assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+
+
+def test_shuffled_long_list(gpu_ctx, oracle_mod, monkeypatch):
+    """A long list in random order (consecutive entries far apart): rt_scene_upload must then keep the
+    Morton-ordered stream for shadows; results equal the oracle's either way, also when the list-ordered
+    stream is forced on such a list."""
+    base = rt.synthetic_scene(n_cubes=700, n_spheres=0)
+    rng = np.random.default_rng(5)
+    order = rng.permutation(len(base.cubes))
+    cubes = [base.cubes[int(i)] for i in order]
+    sc = rt.make_scene(cubes, [], list(base.materials), list(base.lights), base.camera, base.ambient_light, base.sky_0rgb, base.atlas)
+    for forced in (None, "1"):
+        if forced is None:
+            monkeypatch.delenv("RTX950_SHADOW_LIST", raising=False)
+        else:
+            monkeypatch.setenv("RTX950_SHADOW_LIST", forced)
+        f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, 160, 96)
+        assert_parity(gfb, gpl, ofb, opl, f"shuffled long list, shadow list {forced}")
+        assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
 
 
 @pytest.mark.parametrize("depth", [0, 1, 2])
