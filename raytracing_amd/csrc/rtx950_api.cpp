@@ -36,7 +36,6 @@ struct rt_ctx {
     uint32_t* d_cube_perm = nullptr;
     BvhNode* d_bvh = nullptr;
     float* d_sphere_filt = nullptr;
-    uint32_t* d_bvh_items = nullptr;
     float* d_chunk_box = nullptr;
     float* d_cube_filt_list = nullptr;   // list-ordered stream for shadow queries of long lists (when compact)
     uint32_t* d_cube_id_list = nullptr;
@@ -128,8 +127,6 @@ void free_scene(rt_ctx* c)
     c->d_bvh = nullptr;
     (void)hipFree(c->d_sphere_filt);
     c->d_sphere_filt = nullptr;
-    (void)hipFree(c->d_bvh_items);
-    c->d_bvh_items = nullptr;
     (void)hipFree(c->d_chunk_box);
     c->d_chunk_box = nullptr;
     (void)hipFree(c->d_cube_filt_list);
@@ -578,44 +575,17 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
             hbox_list.clear();
         }
     }
-    // BVH for incoherent bundles: items = stream records in Morton order (a long list's stream already is)
-    std::vector<uint32_t> items(n_cubes + 1, 0u);
-    for (size_t j = 0; j < n_cubes; ++j) items[j] = (uint32_t)j;
-    if (!large && n_cubes > 1) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (size_t i = 0; i < n_cubes; ++i) {
-            const float c[3] = {cubes[i].center.x, cubes[i].center.y, cubes[i].center.z};
-            for (int k = 0; k < 3; ++k)
-                if (std::isfinite(c[k])) { lo[k] = std::min(lo[k], (double)c[k]); hi[k] = std::max(hi[k], (double)c[k]); }
-        }
-        auto spread = [](uint32_t v) {
-            v &= 0x3FFu;
-            v = (v | (v << 16)) & 0x030000FFu;
-            v = (v | (v << 8)) & 0x0300F00Fu;
-            v = (v | (v << 4)) & 0x030C30C3u;
-            v = (v | (v << 2)) & 0x09249249u;
-            return v;
-        };
-        std::vector<uint32_t> code(n_cubes, 0u);
-        for (size_t i = 0; i < n_cubes; ++i) {
-            const float c[3] = {cubes[i].center.x, cubes[i].center.y, cubes[i].center.z};
-            uint32_t q[3] = {0u, 0u, 0u};
-            for (int k = 0; k < 3; ++k) {
-                if (!std::isfinite(c[k]) || !(hi[k] > lo[k])) continue;
-                q[k] = (uint32_t)std::min(1023.0, std::max(0.0, ((double)c[k] - lo[k]) / (hi[k] - lo[k]) * 1023.0));
-            }
-            code[i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
-        }
-        std::stable_sort(items.begin(), items.begin() + n_cubes, [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
-    }
+    // BVH for the incoherent bundles of a long list, over the stream records (already in Morton order)
     std::vector<BvhNode> nodes;
-    {
-        // depth-first emission (depth is log2(n)); the skip link is known when the subtree is complete
-        auto box_of = [&](size_t lo_i, size_t hi_i, BvhNode& nd) {
+    uint32_t level = 0u, bvh_depth = 0u;  // pairs on the longest root-to-leaf path = deferred siblings a walk can hold
+    if (large) {
+        auto fill = [&](size_t lo_i, size_t hi_i, BvhNode& nd) {  // box, and the leaf or inner word; link is set by the caller
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             bool finite = true;
+            uint32_t min_idx = 0xFFFFFFFFu;  // lowest list index below this node (shadow pruning and ordering)
             for (size_t j = lo_i; j < hi_i; ++j) {
-                const CubeRec& r = hc[perm[items[j]]];
+                const CubeRec& r = hc[perm[j]];
+                min_idx = std::min(min_idx, perm[j]);
                 const float b[3][2] = {{r.minx, r.maxx}, {r.miny, r.maxy}, {r.minz, r.maxz}};
                 for (int k = 0; k < 3; ++k)
                     for (int e = 0; e < 2; ++e) {
@@ -629,24 +599,28 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
                 h[k] = finite ? std::nextafter((float)std::max(hi[k] - (double)c[k], (double)c[k] - lo[k]), INFINITY) : INFINITY;
             }
             nd.cx = c[0]; nd.cy = c[1]; nd.cz = c[2]; nd.hx = h[0]; nd.hy = h[1]; nd.hz = h[2];
+            nd.link = 0u;
+            nd.first_count = (hi_i - lo_i <= kBvhLeafMax) ? (uint32_t)((lo_i << 3) | (hi_i - lo_i)) : (min_idx << 3);
         };
-        std::function<void(size_t, size_t)> build = [&](size_t lo_i, size_t hi_i) {
-            const size_t me = nodes.size();
+        // pair p holds the two halves of a range; depth is about log2(n), one deferred sibling per level at most
+        std::function<uint32_t(size_t, size_t)> build_pair = [&](size_t lo_i, size_t hi_i) -> uint32_t {
+            ++level;
+            bvh_depth = std::max(bvh_depth, level);
+            const size_t p = nodes.size() / 2;
             nodes.push_back(BvhNode{});
-            box_of(lo_i, hi_i, nodes[me]);
-            if (hi_i - lo_i <= kBvhLeafMax) {
-                nodes[me].first_count = (uint32_t)((lo_i << 3) | (hi_i - lo_i));
-            } else {
-                uint32_t min_idx = 0xFFFFFFFFu;  // lowest list index below this node (shadow pruning)
-                for (size_t j = lo_i; j < hi_i; ++j) min_idx = std::min(min_idx, perm[items[j]]);
-                nodes[me].first_count = min_idx << 3;  // count bits 0: inner node
-                const size_t mid = (lo_i + hi_i) / 2;
-                build(lo_i, mid);
-                build(mid, hi_i);
+            nodes.push_back(BvhNode{});
+            const size_t mid = (lo_i + hi_i) / 2;
+            const size_t range[2][2] = {{lo_i, mid}, {mid, hi_i}};
+            for (int side = 0; side < 2; ++side) {
+                BvhNode nd;
+                fill(range[side][0], range[side][1], nd);
+                if (range[side][1] - range[side][0] > kBvhLeafMax) nd.link = build_pair(range[side][0], range[side][1]);
+                nodes[2 * p + side] = nd;  // after the recursion: the vector may have moved
             }
-            nodes[me].skip = (uint32_t)nodes.size();
+            --level;
+            return (uint32_t)p;
         };
-        if (n_cubes > 0) build(0, n_cubes);
+        build_pair(0, n_cubes);  // n_cubes > kSmallListMax >= 2 * kBvhLeafMax: both halves are non-empty
     }
     double half_sum = 0.0;
     size_t half_n = 0;
@@ -696,7 +670,6 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     if ((rc = upload(ctx, &ctx->d_cube_id_list, hid_list)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_chunk_box_list, hbox_list)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_bvh, nodes)) != RT_OK) return rc;
-    if ((rc = upload(ctx, &ctx->d_bvh_items, items)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_spheres, hs)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_sphere_meta, hsm)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_sphere_filt, hsf)) != RT_OK) return rc;
@@ -717,9 +690,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.shadow_list = shadow_list ? 1u : 0u;
     b.n_chunks = (uint32_t)n_chunks;
     b.bvh = ctx->d_bvh;
-    b.bvh_items = ctx->d_bvh_items;
     b.n_bvh_nodes = (uint32_t)nodes.size();
-    b.coherent_thr = half_n ? (float)(16.0 * half_sum / (double)half_n) : 0.0f;  // 16 average half sizes (swept: 8..16 best)
+    b.coherent_thr = half_n ? (float)(8.0 * half_sum / (double)half_n) : 0.0f;  // 8 average half sizes (swept with the ordered walk: 4..16 within 10 %)
+    if (bvh_depth > kBvhStackMax) b.coherent_thr = INFINITY;  // a list too long for the walk's per-lane stack: every wave takes the chunk traversal
     if (const char* e = getenv("RTX950_COHERENT_SCALE")) b.coherent_thr *= (float)atof(e);  // tuning experiments
     b.spheres = ctx->d_spheres;
     b.sphere_meta = ctx->d_sphere_meta;

@@ -26,14 +26,15 @@ struct CubeRec {
 };
 static_assert(sizeof(CubeRec) == 32, "CubeRec must be one dwordx8");
 
-// Bounding-volume hierarchy over the cubes for incoherent ray bundles (cube_query_bvh): binary, built
-// over the Morton order of the cube centres, stored in depth-first order so that a traversal needs no
-// stack: after a node, go to node + 1 (its first child) if the line meets the box, else to `skip`.
+// Bounding-volume hierarchy over the cubes of a long list, for incoherent ray bundles (cube_query_bvh):
+// binary, median splits of the Morton order of the cube centres, stored as PAIRS of sibling nodes (pair p
+// = nodes 2p and 2p+1, the two children of one inner node; pair 0 = the children of the root), so that
+// one 64-byte fetch brings both boxes a walk has to choose between.
 struct BvhNode {
     float cx, cy, cz;      // box centre
-    uint32_t first_count;  // leaf: (first item << 3) | count (1..4); inner node: lowest list index below it << 3
+    uint32_t first_count;  // leaf: (first stream record << 3) | count (1..kBvhLeafMax); inner node: lowest list index below it << 3
     float hx, hy, hz;      // half extents (rounded up)
-    uint32_t skip;         // next node when this subtree is done or missed; n_bvh_nodes = end
+    uint32_t link;         // inner node: index of the pair holding its children
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be two dwordx4");
 
@@ -66,6 +67,7 @@ constexpr int kMaxLights = 16;
 #define RTX_BVH_LEAF_MAX 2
 #endif
 constexpr uint32_t kBvhLeafMax = RTX_BVH_LEAF_MAX;  // cubes per BVH leaf (3 count bits: at most 7; swept on the 10k-cube world: 1..3 equal, 4 +5 %, 6 +18 %)
+constexpr uint32_t kBvhStackMax = 28;  // deferred siblings per lane: one per level; 2^28 cubes at most
 constexpr uint32_t kRowBlock = 16;  // rows per workgroup tile and per interleave block
 
 struct Params {
@@ -86,9 +88,8 @@ struct Params {
     const float* chunk_box_list;
     uint32_t shadow_list;
     uint32_t n_chunks;
-    // every scene: cube_perm is valid (identity for short lists); bvh_items[k] = stream record of leaf item k
+    // every scene: cube_perm is valid (identity for short lists); bvh: long lists only (n_bvh_nodes = 0 otherwise)
     const BvhNode* bvh;
-    const uint32_t* bvh_items;
     uint32_t n_bvh_nodes;
     float coherent_thr;  // a wave whose cull inflation (2 B dr + wr) exceeds this walks the BVH per lane
     const SphereRec* spheres;

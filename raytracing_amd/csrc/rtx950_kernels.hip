@@ -898,10 +898,47 @@ DEV void cube_query_large(const Params& P, const RayPre& q, const CullPre& cp, b
 // One pass for an INCOHERENT bundle (an 8x8 tile across cube edges after a bounce: lanes going every
 // way).  The wave-level cull keeps nearly every cube for such a wave (measured: all 97 cubes of the
 // diorama, thousands of the 10k-cube world, and these waves are the frame's critical path), so each
-// lane walks the BVH with its own line instead: stackless depth-first order, the separating-axis test
-// of cull_test with the lane's own direction and moment (no radii), the same rounding slack.  Leaf
-// cubes go through cube_candidate per lane.  (Splitting the wave into a few coherent sub-bundles was
+// lane walks the BVH with its own line instead.  (Splitting the wave into a few coherent sub-bundles was
 // tried first: a fifth fewer candidates, 8 % slower.)
+//
+// A lane's walk is a chain of dependent loads, 200-300 of them per walk in a stackless depth-first
+// order over single nodes, and it cannot stop early: the reference's slab test is a LINE test, a line
+// through solid terrain meets a hundred cubes, and only one of them is the answer.  So the walk is
+// ordered: a step fetches a PAIR of sibling boxes (one 64-byte record), tests both with the slab filter
+// (box half extents, the ray's error bound: proven miss only), handles the leaves among them, and goes
+// on with the child that can hold the answer sooner - the smaller entry parameter for a nearest hit,
+// the lower list index for a shadow - deferring the other on a per-lane stack in LDS.  What the answer
+// so far rules out is dropped when fetched: boxes whose entry parameter lies beyond the best distance
+// (every cube in a box has distance >= the box's entry parameter, negative ones included; E = tol/2 as
+// for cubes, the box lies within the scene bounds), subtrees whose lowest list index is not below the
+// blocker.  Unsafe rays have tol = inf and NaN compares false: they visit everything.
+DEV uint32_t* bvh_stack()
+{
+    __shared__ uint32_t s[kBvhStackMax * 64u];  // [level][lane]; only kernels of long lists carry it
+    return s;
+}
+
+struct BoxTest { float lo; bool hit; };
+DEV BoxTest box_slab(const RayPre& q, f32x4 c, f32x4 h)
+{
+    const float mx = __builtin_fmaf(c[0], q.r_xy[0], q.c_xy[0]), my = __builtin_fmaf(c[1], q.r_xy[1], q.c_xy[1]);
+    const float mz = __builtin_fmaf(c[2], q.rc_z[0], q.rc_z[1]);
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(h[0], q.na_xy[0], mx), __builtin_fmaf(h[1], q.na_xy[1], my)),
+                                     __builtin_fmaf(h[2], q.a_z_pm[0], mz));
+    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaf(h[0], -q.na_xy[0], mx), __builtin_fmaf(h[1], -q.na_xy[1], my)),
+                                     __builtin_fmaf(h[2], q.a_z_pm[1], mz));
+    return BoxTest{lo, !(lo - hi > q.tol)};  // NaN -> hit
+}
+// A direction component that is exactly zero does not constrain the filter's interval (ray_pre), but the
+// reference's test fails for every cube whose slab on that axis does not hold the origin (zero_axis_check):
+// a box whose slab the origin misses by more than zdelta holds no cube that passes.
+DEV bool box_zero_axis_miss(const RayPre& q, V3 o, f32x4 c, f32x4 h)
+{
+    const bool zx = (q.zbits & 1u) != 0u, zy = (q.zbits & 2u) != 0u, zz = (q.zbits & 4u) != 0u;
+    return (zx && __builtin_fabsf(c[0] - o.x) > h[0] + q.zdelta) || (zy && __builtin_fabsf(c[1] - o.y) > h[1] + q.zdelta) ||
+           (zz && __builtin_fabsf(c[2] - o.z) > h[2] + q.zdelta);
+}
+
 template <int MODE>
 DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
@@ -910,71 +947,81 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
     PROF_COUNT(2, 65536);  // profile builds: BVH walks in the high half of counter 2
     PROF_KCOUNT(qk, 1);
     PROF_MARK(PH_PRE);
-    const float wxy = o.x * d.y - o.y * d.x, wyz = o.y * d.z - o.z * d.y, wzx = o.z * d.x - o.x * d.z;
-    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
-    const float om = __builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fmaxf(__builtin_fabsf(o.y), __builtin_fabsf(o.z)));
-    const float slack = 0x1p-17f * (P.bound_max + om + 1.0f) * __builtin_fmaxf(ax + ay + az, 1.0f);  // as in cull_pre
-    const uint32_t end = P.n_bvh_nodes;
+    const uint32_t lane = threadIdx.x & 63u;
     const f32x4* nodes = (const f32x4*)P.bvh;
     const f32x4* filt = (const f32x4*)P.cube_filt;
-    uint32_t node = active ? 0u : end;
-    while (wave_any(node != end)) {
-        const bool on = node != end;
-        const uint32_t ni = on ? node : 0u;
-        const f32x4 a = nodes[(size_t)ni * 2u], b = nodes[(size_t)ni * 2u + 1u];
-        const float a3 = a[3], b3 = b[3];  // scalar copies first: see the note at u2f
-        const uint32_t first_count = __builtin_bit_cast(uint32_t, a3), skip = __builtin_bit_cast(uint32_t, b3);
-        const float gxy = __builtin_fmaf(a[0], d.y, __builtin_fmaf(-a[1], d.x, -wxy));
-        const float lxy = __builtin_fmaf(b[0], ay, __builtin_fmaf(b[1], ax, slack));
-        const float gyz = __builtin_fmaf(a[1], d.z, __builtin_fmaf(-a[2], d.y, -wyz));
-        const float lyz = __builtin_fmaf(b[1], az, __builtin_fmaf(b[2], ay, slack));
-        const float gzx = __builtin_fmaf(a[2], d.x, __builtin_fmaf(-a[0], d.z, -wzx));
-        const float lzx = __builtin_fmaf(b[2], ax, __builtin_fmaf(b[0], az, slack));
-        const bool sep = (__builtin_fabsf(gxy) > lxy) || (__builtin_fabsf(gyz) > lyz) || (__builtin_fabsf(gzx) > lzx);
-        bool meet = on && (q.wild || !sep);  // NaN compares false -> meet
-        const uint32_t cnt = first_count & 7u, first = first_count >> 3;
-        // Prune subtrees that cannot change the lane's result.  Every cube in the box has distance
-        // (cube.rs:145: tmin, or tmax if tmin < 0) >= the box's own entry parameter lo, negative ones
-        // included; lo comes from the slab filter with the box's half extents (same error bound E =
-        // tol/2, the box lies within the scene bounds).  A cube with approximate distance above
-        // b1 + tol is neither the winner nor "contested", one with exact distance above `best` cannot
-        // win or tie.  Unsafe rays have tol = inf and NaN compares false: no pruning.  Shadow: only
-        // the lowest list index matters, and an inner node carries the lowest index below it.
-        if constexpr (MODE == Q_SHADOW) {
-            meet = meet && !(cnt == 0u && first >= st.blocker);
-        } else {
-            const float nx = __builtin_fmaf(b[0], q.na_xy[0], __builtin_fmaf(a[0], q.r_xy[0], q.c_xy[0]));
-            const float ny = __builtin_fmaf(b[1], q.na_xy[1], __builtin_fmaf(a[1], q.r_xy[1], q.c_xy[1]));
-            const float nz = __builtin_fmaf(b[2], q.a_z_pm[0], __builtin_fmaf(a[2], q.rc_z[0], q.rc_z[1]));
-            const float lo = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
-            if constexpr (MODE == Q_NEAREST) meet = meet && !(lo > st.b1 + 2.0f * q.tol);
-            else meet = meet && !(lo - q.tol > st.best);
+    uint32_t* stack = bvh_stack() + lane;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t pair = active ? 0u : kNone;  // pair 0: the children of the root
+    uint32_t sp = 0u;
+    while (wave_any(pair != kNone)) {
+        PROF_COUNT(MODE == Q_SHADOW ? 4 : 3, 1);  // profile builds: walk steps (drown the few amb counts of these slots)
+        const bool on = pair != kNone;
+        const size_t pi = on ? (size_t)pair * 4u : 0u;
+        const f32x4 ac = nodes[pi], ah = nodes[pi + 1u], bc = nodes[pi + 2u], bh = nodes[pi + 3u];
+        const float ac3 = ac[3], ah3 = ah[3], bc3 = bc[3], bh3 = bh[3];  // scalar copies first: see the note at u2f
+        const uint32_t fca = __builtin_bit_cast(uint32_t, ac3), fcb = __builtin_bit_cast(uint32_t, bc3);
+        const uint32_t link_a = __builtin_bit_cast(uint32_t, ah3), link_b = __builtin_bit_cast(uint32_t, bh3);
+        const uint32_t cnt_a = fca & 7u, cnt_b = fcb & 7u, first_a = fca >> 3, first_b = fcb >> 3;
+        const BoxTest ta = box_slab(q, ac, ah), tb = box_slab(q, bc, bh);
+        bool meet_a = on && ta.hit, meet_b = on && tb.hit;
+        if (any_zero) {
+            meet_a = meet_a && !box_zero_axis_miss(q, o, ac, ah);
+            meet_b = meet_b && !box_zero_axis_miss(q, o, bc, bh);
         }
-        const bool leaf = meet && (cnt != 0u);
+        if constexpr (MODE == Q_SHADOW) {
+            meet_a = meet_a && !(cnt_a == 0u && first_a >= st.blocker);
+            meet_b = meet_b && !(cnt_b == 0u && first_b >= st.blocker);
+        } else if constexpr (MODE == Q_NEAREST) {
+            const float limit = st.b1 + 2.0f * q.tol;
+            meet_a = meet_a && !(ta.lo > limit);
+            meet_b = meet_b && !(tb.lo > limit);
+        } else {
+            meet_a = meet_a && !(ta.lo - q.tol > st.best);
+            meet_b = meet_b && !(tb.lo - q.tol > st.best);
+        }
+        const bool leaf_a = meet_a && (cnt_a != 0u), leaf_b = meet_b && (cnt_b != 0u);
         PROF_MARK(PH_CULL);
-        if (wave_any(leaf)) {
-            // A lane's walk is a chain of dependent loads and these waves are the frame's critical path: the
-            // leaf's records are fetched together, and a long list's items are its stream records
-            // themselves (rt_scene_upload: bvh_items is the identity there), one level of indirection less.
-            f32x4 rec[kBvhLeafMax];
-            uint32_t idx[kBvhLeafMax], ids[kBvhLeafMax];
+        if (wave_any(leaf_a || leaf_b)) {
+            // the records of both leaves are fetched together (a long list's stream records are the BVH's items)
+            f32x4 rec[2u * kBvhLeafMax];
+            uint32_t idx[2u * kBvhLeafMax], ids[2u * kBvhLeafMax];
 #pragma unroll
-            for (uint32_t c = 0; c < kBvhLeafMax; ++c) {
-                const uint32_t sp = (leaf && c < cnt) ? first + c : 0u;
-                rec[c] = filt[sp];
-                idx[c] = P.cube_perm[sp];
+            for (uint32_t c = 0; c < 2u * kBvhLeafMax; ++c) {
+                const bool second = c >= kBvhLeafMax;
+                const uint32_t k = second ? c - kBvhLeafMax : c;
+                const bool lc = second ? (leaf_b && k < cnt_b) : (leaf_a && k < cnt_a);
+                const uint32_t sp_rec = lc ? (second ? first_b : first_a) + k : 0u;
+                rec[c] = filt[sp_rec];
+                idx[c] = P.cube_perm[sp_rec];
                 ids[c] = 0u;
-                if constexpr (MODE == Q_SHADOW) ids[c] = P.cube_id[sp];
+                if constexpr (MODE == Q_SHADOW) ids[c] = P.cube_id[sp_rec];
             }
 #pragma unroll
-            for (uint32_t c = 0; c < kBvhLeafMax; ++c) {
-                const bool lc = leaf && (c < cnt);
-                if (!wave_any(lc)) break;
-                cube_candidate<MODE, false>(P, q, lc, any_zero, o, d, impact_id, idx[c], ids[c], rec[c][0], rec[c][1], rec[c][2], rec[c][3], st PROF_PASS);
+            for (uint32_t c = 0; c < 2u * kBvhLeafMax; ++c) {
+                const bool second = c >= kBvhLeafMax;
+                const uint32_t k = second ? c - kBvhLeafMax : c;
+                const bool lc = second ? (leaf_b && k < cnt_b) : (leaf_a && k < cnt_a);
+                if (wave_any(lc))
+                    cube_candidate<MODE, false>(P, q, lc, any_zero, o, d, impact_id, idx[c], ids[c], rec[c][0], rec[c][1], rec[c][2], rec[c][3], st PROF_PASS);
             }
             PROF_MARK(PH_CAND);
         }
-        node = on ? ((meet && cnt == 0u) ? node + 1u : skip) : end;  // indices only grow: the walk ends
+        // inner children that are still worth a visit: the nearer / lower-indexed one next, the other deferred
+        const bool in_a = meet_a && (cnt_a == 0u), in_b = meet_b && (cnt_b == 0u);
+        bool a_first;
+        if constexpr (MODE == Q_SHADOW) a_first = !(first_b < first_a);
+        else a_first = !(tb.lo < ta.lo);
+        const bool both = in_a && in_b;
+        if (both) stack[sp * 64u] = a_first ? link_b : link_a;
+        const bool pop = on && !(in_a || in_b) && (sp != 0u);
+        const uint32_t popped = stack[(pop ? sp - 1u : 0u) * 64u];
+        uint32_t next = kNone;
+        next = pop ? popped : next;
+        next = in_b ? link_b : next;
+        next = (in_a && (a_first || !in_b)) ? link_a : next;
+        sp = both ? sp + 1u : (pop ? sp - 1u : sp);
+        pair = on ? next : kNone;
     }
 }
 
