@@ -600,7 +600,13 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
             }
             nd.cx = c[0]; nd.cy = c[1]; nd.cz = c[2]; nd.hx = h[0]; nd.hy = h[1]; nd.hz = h[2];
             nd.link = 0u;
-            nd.first_count = (hi_i - lo_i <= kBvhLeafMax) ? (uint32_t)((lo_i << 3) | (hi_i - lo_i)) : (min_idx << 3);
+            nd.first_count = min_idx << 3;
+            if (hi_i - lo_i == 1) {  // a leaf is its cube: the cull stream's record (centre, |half size|), list index, id
+                nd.cx = hf[4 * lo_i + 0]; nd.cy = hf[4 * lo_i + 1]; nd.cz = hf[4 * lo_i + 2];
+                nd.hx = nd.hy = nd.hz = hf[4 * lo_i + 3];
+                nd.first_count = (perm[lo_i] << 3) | 1u;
+                nd.link = hid[lo_i];
+            }
         };
         // pair p holds the two halves of a range; depth is about log2(n), one deferred sibling per level at most
         std::function<uint32_t(size_t, size_t)> build_pair = [&](size_t lo_i, size_t hi_i) -> uint32_t {
@@ -614,13 +620,13 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
             for (int side = 0; side < 2; ++side) {
                 BvhNode nd;
                 fill(range[side][0], range[side][1], nd);
-                if (range[side][1] - range[side][0] > kBvhLeafMax) nd.link = build_pair(range[side][0], range[side][1]);
+                if (range[side][1] - range[side][0] > 1) nd.link = build_pair(range[side][0], range[side][1]);
                 nodes[2 * p + side] = nd;  // after the recursion: the vector may have moved
             }
             --level;
             return (uint32_t)p;
         };
-        build_pair(0, n_cubes);  // n_cubes > kSmallListMax >= 2 * kBvhLeafMax: both halves are non-empty
+        build_pair(0, n_cubes);  // n_cubes > kSmallListMax >= 2: both halves are non-empty
     }
     double half_sum = 0.0;
     size_t half_n = 0;

@@ -31,10 +31,10 @@ static_assert(sizeof(CubeRec) == 32, "CubeRec must be one dwordx8");
 // = nodes 2p and 2p+1, the two children of one inner node; pair 0 = the children of the root), so that
 // one 64-byte fetch brings both boxes a walk has to choose between.
 struct BvhNode {
-    float cx, cy, cz;      // box centre
-    uint32_t first_count;  // leaf: (first stream record << 3) | count (1..kBvhLeafMax); inner node: lowest list index below it << 3
-    float hx, hy, hz;      // half extents (rounded up)
-    uint32_t link;         // inner node: index of the pair holding its children
+    float cx, cy, cz;      // box centre; leaf: the cube's centre
+    uint32_t first_count;  // leaf (one cube): (its list index << 3) | 1; inner node: lowest list index below it << 3
+    float hx, hy, hz;      // half extents (rounded up); leaf: the cube's |half size| three times
+    uint32_t link;         // inner node: index of the pair holding its children; leaf: the cube's id
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be two dwordx4");
 
@@ -63,10 +63,6 @@ struct LightRec {
 };
 
 constexpr int kMaxLights = 16;
-#ifndef RTX_BVH_LEAF_MAX
-#define RTX_BVH_LEAF_MAX 2
-#endif
-constexpr uint32_t kBvhLeafMax = RTX_BVH_LEAF_MAX;  // cubes per BVH leaf (3 count bits: at most 7; swept on the 10k-cube world: 1..3 equal, 4 +5 %, 6 +18 %)
 constexpr uint32_t kBvhStackMax = 28;  // deferred siblings per lane: one per level; 2^28 cubes at most
 constexpr uint32_t kRowBlock = 16;  // rows per workgroup tile and per interleave block
 

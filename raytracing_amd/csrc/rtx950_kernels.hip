@@ -905,7 +905,8 @@ DEV void cube_query_large(const Params& P, const RayPre& q, const CullPre& cp, b
 // order over single nodes, and it cannot stop early: the reference's slab test is a LINE test, a line
 // through solid terrain meets a hundred cubes, and only one of them is the answer.  So the walk is
 // ordered: a step fetches a PAIR of sibling boxes (one 64-byte record), tests both with the slab filter
-// (box half extents, the ray's error bound: proven miss only), handles the leaves among them, and goes
+// (box half extents, the ray's error bound: proven miss only), handles the leaves among them (a leaf is one
+// cube and carries its record: centre, half size, list index, id), and goes
 // on with the child that can hold the answer sooner - the smaller entry parameter for a nearest hit,
 // the lower list index for a shadow - deferring the other on a per-lane stack in LDS.  What the answer
 // so far rules out is dropped when fetched: boxes whose entry parameter lies beyond the best distance
@@ -949,7 +950,6 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
     PROF_MARK(PH_PRE);
     const uint32_t lane = threadIdx.x & 63u;
     const f32x4* nodes = (const f32x4*)P.bvh;
-    const f32x4* filt = (const f32x4*)P.cube_filt;
     uint32_t* stack = bvh_stack() + lane;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     uint32_t pair = active ? 0u : kNone;  // pair 0: the children of the root
@@ -982,31 +982,12 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
         }
         const bool leaf_a = meet_a && (cnt_a != 0u), leaf_b = meet_b && (cnt_b != 0u);
         PROF_MARK(PH_CULL);
-        if (wave_any(leaf_a || leaf_b)) {
-            // the records of both leaves are fetched together (a long list's stream records are the BVH's items)
-            f32x4 rec[2u * kBvhLeafMax];
-            uint32_t idx[2u * kBvhLeafMax], ids[2u * kBvhLeafMax];
-#pragma unroll
-            for (uint32_t c = 0; c < 2u * kBvhLeafMax; ++c) {
-                const bool second = c >= kBvhLeafMax;
-                const uint32_t k = second ? c - kBvhLeafMax : c;
-                const bool lc = second ? (leaf_b && k < cnt_b) : (leaf_a && k < cnt_a);
-                const uint32_t sp_rec = lc ? (second ? first_b : first_a) + k : 0u;
-                rec[c] = filt[sp_rec];
-                idx[c] = P.cube_perm[sp_rec];
-                ids[c] = 0u;
-                if constexpr (MODE == Q_SHADOW) ids[c] = P.cube_id[sp_rec];
-            }
-#pragma unroll
-            for (uint32_t c = 0; c < 2u * kBvhLeafMax; ++c) {
-                const bool second = c >= kBvhLeafMax;
-                const uint32_t k = second ? c - kBvhLeafMax : c;
-                const bool lc = second ? (leaf_b && k < cnt_b) : (leaf_a && k < cnt_a);
-                if (wave_any(lc))
-                    cube_candidate<MODE, false>(P, q, lc, any_zero, o, d, impact_id, idx[c], ids[c], rec[c][0], rec[c][1], rec[c][2], rec[c][3], st PROF_PASS);
-            }
-            PROF_MARK(PH_CAND);
-        }
+        // a leaf IS its cube (centre, half size, list index and id in the node): no further fetch
+        if (wave_any(leaf_a))
+            cube_candidate<MODE, false>(P, q, leaf_a, any_zero, o, d, impact_id, first_a, link_a, ac[0], ac[1], ac[2], ah[0], st PROF_PASS);
+        if (wave_any(leaf_b))
+            cube_candidate<MODE, false>(P, q, leaf_b, any_zero, o, d, impact_id, first_b, link_b, bc[0], bc[1], bc[2], bh[0], st PROF_PASS);
+        PROF_MARK(PH_CAND);
         // inner children that are still worth a visit: the nearer / lower-indexed one next, the other deferred
         const bool in_a = meet_a && (cnt_a == 0u), in_b = meet_b && (cnt_b == 0u);
         bool a_first;
