@@ -31,6 +31,10 @@ struct rt_ctx {
     CubeRec* d_cubes = nullptr;
     float* d_cube_filt = nullptr;
     std::vector<float> h_cube_box;  // centre xyz + |half size| per cube, list order (rt_frame_row_extent)
+    // rt_frame_row_extent's last answer (a host loop over all cubes; hosts ask once per frame, cameras often stand still)
+    bool extent_valid = false;
+    rt_camera extent_camera{};
+    uint32_t extent_dims[4] = {0, 0, 0, 0}, extent_rows[2] = {0, 0};
     size_t h_n_spheres = 0;
     uint32_t* d_cube_id = nullptr;
     uint32_t* d_cube_perm = nullptr;
@@ -510,6 +514,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
         ctx->h_cube_box[4 * i + 2] = cubes[i].center.z; ctx->h_cube_box[4 * i + 3] = std::fabs(cubes[i].size / 2.0f);
     }
     ctx->h_n_spheres = n_spheres;
+    ctx->extent_valid = false;
     const size_t n_chunks = large ? (n_cubes + 63) / 64 : 0;
     const size_t n_box = ((n_chunks + 63) / 64) * 64 + 64;
     // bounding box per chunk of 64 consecutive records of a stream given by its list indices; returns the
@@ -923,10 +928,24 @@ int rt_frame_row_extent(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_y_firs
     *out_y_first = frame->y0;
     *out_y_end = frame->y1;
     if (ctx->h_n_spheres != 0) return RT_OK;  // the sphere pass is traced everywhere
+    const uint32_t dims[4] = {frame->width, frame->height, frame->y0, frame->y1};
+    if (ctx->extent_valid && std::memcmp(&ctx->extent_camera, &frame->camera, sizeof(rt_camera)) == 0 &&
+        std::memcmp(ctx->extent_dims, dims, sizeof(dims)) == 0) {
+        *out_y_first = ctx->extent_rows[0];
+        *out_y_end = ctx->extent_rows[1];
+        return RT_OK;
+    }
+    auto remember = [&]() {
+        ctx->extent_camera = frame->camera;
+        std::memcpy(ctx->extent_dims, dims, sizeof(dims));
+        ctx->extent_rows[0] = *out_y_first;
+        ctx->extent_rows[1] = *out_y_end;
+        ctx->extent_valid = true;
+    };
     Params p;
     fill_frame(ctx, frame, p);
     TileParams t;
-    if (!projection_setup(p, t)) return RT_OK;
+    if (!projection_setup(p, t)) { remember(); return RT_OK; }
     const double* r = t.right; const double* u = t.up; const double* f = t.fwd;
     double lo = 1e300, hi = -1e300;
     const size_t n = ctx->h_cube_box.size() / 4;
@@ -942,7 +961,7 @@ int rt_frame_row_extent(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_y_firs
             const double len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
             const double py = (1.0 - b / c) * (double)t.height * 0.5;
             // a corner beside or behind the eye (the slab test is a line test), or NaN: no conclusion
-            if (!(c > 1e-3 * len) || !(c > 16.0 * t.pad) || !(std::fabs(py) < 1e9)) return RT_OK;
+            if (!(c > 1e-3 * len) || !(c > 16.0 * t.pad) || !(std::fabs(py) < 1e9)) { remember(); return RT_OK; }
             lo = std::min(lo, py);
             hi = std::max(hi, py);
         }
@@ -956,6 +975,7 @@ int rt_frame_row_extent(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_y_firs
     }
     *out_y_first = y_first;
     *out_y_end = y_end;
+    remember();
     return RT_OK;
 }
 
