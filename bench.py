@@ -118,8 +118,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU baseline sample; 0 disables it")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--inflight", type=int, default=0,
-                    help="frames in flight per GPU (one library context and stream each); 0 = 1 at N=1 (launches do not overlap: "
-                         "the roofline's kernel time is a kernel alone on the GPU), 2 at N>1")
+                    help="frames in flight per GPU (one library context and stream each: the next frame starts under the current "
+                         "frame's slowest tiles); 0 = 1 at N=1 (launches do not overlap: the roofline's kernel time is a kernel "
+                         "alone on the GPU), 2 at N>1")
     ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
     args = ap.parse_args()
 
@@ -165,8 +166,9 @@ def main():
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
     with torch.cuda.stream(ext):
         inflight = args.inflight if args.inflight > 0 else (2 if world > 1 else 1)
-        piped = world > 1 or inflight > 1
+        piped = world > 1  # N = 1 renders straight into its frames: no message, no scatter
         fg = FrameGather(H, W, world, rank, dev, depth=inflight)
+        outs = fg.locals  # N = 1: one whole frame per frame in flight ([max_part_rows, W] = [H, W] there)
     out = fg.local  # [max_part_rows, W] int32, padded so every rank sends the same size
     # N > 1: frame f+1 renders while frame f is gathered to GPU0 and while f's slowest tiles finish (a rank
     # holds 1/N of the work but the whole critical path); every frame is whole on GPU0 before the timed
@@ -174,7 +176,7 @@ def main():
     # the null stream that is one hardware queue per stream (GPU_MAX_HW_QUEUES = 4)
     # and so does its slowest tile: one library context (own stream, queue, tile costs) per message buffer
     ctxs, streams = [ctx], [ext]
-    if piped:
+    if inflight > 1:
         for _ in range(len(fg.locals) - 1):
             c2 = rt.Context(device_index)
             c2.upload(scene)
@@ -183,14 +185,16 @@ def main():
     pipe = FramePipeline(fg, lambda buf, slot: ctxs[slot].render_device(frame, buf.data_ptr(), n_parts=world, part=rank), streams) if piped else None
 
     orbit = bool(kwargs.get("orbit"))
-    state = {"cam": scene.camera}
+    state = {"cam": scene.camera, "n": 0}
 
     def step():
         if orbit:  # every rank advances the same camera
             state["cam"] = rt.rotate_cam(state["cam"], 3.14159265358979 / 180.0, 0.0)
             frame.camera = state["cam"]
         if pipe is None:
-            ctx.render_device(frame, out.data_ptr())
+            slot = state["n"] % inflight  # N = 1 with --inflight k: frames alternate over k contexts (streams)
+            state["n"] += 1
+            ctxs[slot].render_device(frame, outs[slot].data_ptr())
         else:
             # render this rank's blocks, then (gather stream) RCCL gather of the rows that can hold geometry
             # to GPU0 + scatter into frame order; GPU0 paints the sky rows itself (rt_frame_row_extent)
@@ -239,15 +243,18 @@ def main():
     if rank == 0:
         if orbit:
             frame.camera = scene.camera
-        if pipe is not None:
-            # the gathered frame against one rendered whole on this GPU (same camera: the last step's)
-            pipe.drain()
+        if pipe is not None or inflight > 1:
+            # the gathered (or last in-flight) frame against one rendered whole on this GPU (same camera: the last step's)
+            last = outs[(state["n"] - 1) % inflight]
+            if pipe is not None:
+                pipe.drain()
+                last = fg.frame
             whole = torch.zeros((H, W), dtype=torch.int32, device=dev)
             ctx.render_device(frame if not orbit else scene.frame(W, H, camera=state["cam"]), whole.data_ptr())
             ctx.sync()
             torch.cuda.synchronize(dev)
-            if not torch.equal(whole, fg.frame):
-                bad = int((whole != fg.frame).sum().item())
+            if not torch.equal(whole, last):
+                bad = int((whole != last).sum().item())
                 print(f"bench.py: the frame gathered from {world} rank(s) differs from the single-GPU frame in {bad} pixels", file=sys.stderr)
                 sys.exit(3)
         total = ctx.count_rays(frame)
@@ -292,12 +299,34 @@ def main():
                 "note": "algorithmic FP32 ops of the reference's brute-force walk: 26/ray-cube test + 25/ray-sphere test + 60*lights/shaded hit (SURVEY 8d), rank 0's launch; the kernel proves most tests fail without executing them, so frac can exceed 1 (executed view: valu_busy_frac_pmc)",
             },
         }
-        if pipe is not None:
+        if pipe is not None or inflight > 1:
             result["config"]["frame_check"] = "gathered frame identical to the frame rendered whole on GPU0 (checked after the timed region)"
         if world == 1 and args.cpu_seconds > 0:
             cb = cpu_baseline(scene, W, H, args.cpu_seconds, args.cpu_threads)
             result["cpu_baseline"] = cb
             result["config"]["gpu_over_cpu_reference_accounting"] = (rays_ref * args.steps / elapsed / 1e6) / cb["value"]
+        if world == 1 and inflight == 1:
+            # The same workload with two frames in flight (a second library context = a second stream; frames
+            # alternate), measured apart so that the line above and its roofline stay "one kernel alone on the
+            # GPU": the next frame's launches then run under the current frame's slowest tiles.
+            c2 = rt.Context(device_index)
+            c2.upload(scene)
+            pair_ctx = [ctx, c2]
+            pair_out = [out, torch.zeros_like(out)]
+            if orbit:
+                frame.camera = scene.camera
+            for i in range(4):
+                pair_ctx[i % 2].render_device(frame, pair_out[i % 2].data_ptr())
+            ctx.sync(); c2.sync()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                pair_ctx[i % 2].render_device(frame, pair_out[i % 2].data_ptr())
+            ctx.sync(); c2.sync()
+            dt = (time.perf_counter() - t1) / args.steps
+            same = bool(torch.equal(pair_out[0], pair_out[1]))
+            c2.close()
+            result["config"]["two_frames_in_flight"] = {"ms_per_step": dt * 1e3, "value": rays_uniq / dt / 1e6, "unit": "Mrays/s",
+                                                        "frames_identical": same, "note": "--inflight 2 makes this the timed mode"}
         if world == 1 and args.extra:
             extra = {}
             for name in ("minecraft_1080p", "minecraft_water_4k"):
