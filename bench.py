@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s of the MI355X render path (BASELINE.json metric) on N GPUs of one node.
 
-A step = one frame of the workload rendered through the C-ABI (rt_render_device_part): at N>1 the
+A step = one frame of the workload rendered through the C-ABI (rt_render_device_part).  Two frames are
+in flight per GPU (two library contexts = two streams, frames alternate; --inflight), every frame
+complete before the timed region ends.  At N>1 the
 frame's 16-row blocks are dealt round-robin to the ranks (strong scaling, total work fixed) and each
 rank's compact band (the rows that can hold geometry) is gathered to GPU0 over RCCL/xGMI inside the
 timed region, overlapped with the rendering of the next frame.
@@ -119,8 +121,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (one library context and stream each: the next frame starts under the current "
-                         "frame's slowest tiles); 0 = 1 at N=1 (launches do not overlap: the roofline's kernel time is a kernel "
-                         "alone on the GPU), 2 at N>1")
+                         "frame's slowest tiles); 0 = the default of 2 at every N; 1 = strictly one frame at a time")
     ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
     args = ap.parse_args()
 
@@ -165,7 +166,7 @@ def main():
     # the library's own stream as a torch stream: the gather of a frame is ordered after its render by events
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
     with torch.cuda.stream(ext):
-        inflight = args.inflight if args.inflight > 0 else (2 if world > 1 else 1)
+        inflight = args.inflight if args.inflight > 0 else 2
         piped = world > 1  # N = 1 renders straight into its frames: no message, no scatter
         fg = FrameGather(H, W, world, rank, dev, depth=inflight)
         outs = fg.locals  # N = 1: one whole frame per frame in flight ([max_part_rows, W] = [H, W] there)
@@ -305,46 +306,48 @@ def main():
             cb = cpu_baseline(scene, W, H, args.cpu_seconds, args.cpu_threads)
             result["cpu_baseline"] = cb
             result["config"]["gpu_over_cpu_reference_accounting"] = (rays_ref * args.steps / elapsed / 1e6) / cb["value"]
-        if world == 1 and inflight == 1:
-            # The same workload with two frames in flight (a second library context = a second stream; frames
-            # alternate), measured apart so that the line above and its roofline stay "one kernel alone on the
-            # GPU": the next frame's launches then run under the current frame's slowest tiles.
-            c2 = rt.Context(device_index)
-            c2.upload(scene)
-            pair_ctx = [ctx, c2]
-            pair_out = [out, torch.zeros_like(out)]
+        if world == 1 and inflight > 1:
+            # The same workload strictly one frame at a time (one context, one stream), measured apart: how long a
+            # frame takes from launch to completion, and the render kernel's duration alone on the GPU.
             if orbit:
                 frame.camera = scene.camera
-            for i in range(4):
-                pair_ctx[i % 2].render_device(frame, pair_out[i % 2].data_ptr())
-            ctx.sync(); c2.sync()
+            for _ in range(3):
+                ctx.render_device(frame, out.data_ptr())
+            ctx.sync()
+            ctx.enable_timing(True)
+            ctx.kernel_time_ms()
             t1 = time.perf_counter()
-            for i in range(args.steps):
-                pair_ctx[i % 2].render_device(frame, pair_out[i % 2].data_ptr())
-            ctx.sync(); c2.sync()
+            for _ in range(args.steps):
+                ctx.render_device(frame, out.data_ptr())
+            ctx.sync()
             dt = (time.perf_counter() - t1) / args.steps
-            same = bool(torch.equal(pair_out[0], pair_out[1]))
-            c2.close()
-            result["config"]["two_frames_in_flight"] = {"ms_per_step": dt * 1e3, "value": rays_uniq / dt / 1e6, "unit": "Mrays/s",
-                                                        "frames_identical": same, "note": "--inflight 2 makes this the timed mode"}
+            solo_ms, _ = ctx.kernel_time_ms()
+            ctx.enable_timing(False)
+            result["config"]["one_frame_in_flight"] = {"ms_per_step": dt * 1e3, "value": rays_uniq / dt / 1e6, "unit": "Mrays/s",
+                                                       "kernel_avg_ms": solo_ms,
+                                                       "roofline_frac": (flops_launch / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if solo_ms > 0 else None,
+                                                       "note": "--inflight 1 makes this the timed mode"}
         if world == 1 and args.extra:
             extra = {}
             for name in ("minecraft_1080p", "minecraft_water_4k"):
                 k2, kw2, w2, h2 = WORKLOADS[name]
                 sc2 = make_scene(rt, k2, kw2)
-                ctx.upload(sc2)
+                for c in ctxs:
+                    c.upload(sc2)
                 f2 = sc2.frame(w2, h2)
-                o2 = torch.zeros((h2, w2), dtype=torch.int32, device=dev)
-                for _ in range(2):
-                    ctx.render_device(f2, o2.data_ptr())
-                ctx.sync()
+                o2 = [torch.zeros((h2, w2), dtype=torch.int32, device=dev) for _ in ctxs]
+                for i in range(2 * len(ctxs)):
+                    ctxs[i % len(ctxs)].render_device(f2, o2[i % len(ctxs)].data_ptr())
+                for c in ctxs:
+                    c.sync()
                 t1 = time.perf_counter()
-                for _ in range(10):
-                    ctx.render_device(f2, o2.data_ptr())
-                ctx.sync()
-                dt = (time.perf_counter() - t1) / 10
+                for i in range(10 * len(ctxs)):
+                    ctxs[i % len(ctxs)].render_device(f2, o2[i % len(ctxs)].data_ptr())
+                for c in ctxs:
+                    c.sync()
+                dt = (time.perf_counter() - t1) / (10 * len(ctxs))
                 c2 = ctx.count_rays(f2)
-                extra[name] = {"ms_per_frame": dt * 1e3, "mrays_per_s": c2.rays / dt / 1e6, "rays_per_frame_unique": c2.rays}
+                extra[name] = {"ms_per_frame": dt * 1e3, "mrays_per_s": c2.rays / dt / 1e6, "rays_per_frame_unique": c2.rays, "frames_in_flight": len(ctxs)}
             result["config"]["extra"] = extra
         print(json.dumps(result), flush=True)
     if world > 1:
