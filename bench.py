@@ -206,6 +206,7 @@ def main():
             c.sync()
         torch.cuda.synchronize(dev)
 
+    torch.cuda.synchronize(dev)  # torch's buffer fills are not ordered against the library's streams
     for _ in range(args.warmup):
         step()
     sync()
@@ -250,7 +251,8 @@ def main():
             if pipe is not None:
                 pipe.drain()
                 last = fg.frame
-            whole = torch.zeros((H, W), dtype=torch.int32, device=dev)
+            whole = torch.empty((H, W), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)  # nothing of torch's may still be writing when the library's stream renders into it
             ctx.render_device(frame if not orbit else scene.frame(W, H, camera=state["cam"]), whole.data_ptr())
             ctx.sync()
             torch.cuda.synchronize(dev)
@@ -336,6 +338,7 @@ def main():
                     c.upload(sc2)
                 f2 = sc2.frame(w2, h2)
                 o2 = [torch.zeros((h2, w2), dtype=torch.int32, device=dev) for _ in ctxs]
+                torch.cuda.synchronize(dev)  # torch's fills are not ordered against the library's streams
                 for i in range(2 * len(ctxs)):
                     ctxs[i % len(ctxs)].render_device(f2, o2[i % len(ctxs)].data_ptr())
                 for c in ctxs:

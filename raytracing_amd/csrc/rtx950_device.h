@@ -136,6 +136,10 @@ struct Params {
     uint32_t* hit_sphere;
     uint32_t* tree_hash;
     unsigned long long* counters;  // 10 x u64, rt_counters order
+    // 1: `out` holds the sky colour everywhere already (a fill ahead of the launches): build_queue lists no
+    // tile that is only painted, so the render kernel has no paint groups.  (Last member on purpose: the
+    // render kernel does not read it, and its code stays the same to the instruction.)
+    uint32_t prefilled;
 };
 
 // classify_tiles: one wave per cube projects the cube's padded corners through the frame's camera and

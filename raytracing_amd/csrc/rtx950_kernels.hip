@@ -1421,11 +1421,16 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
     if (threadIdx.x <= kCostClasses) n_cls[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t rank = 0u;
-    if (in_band) rank = atomicAdd(&n_cls[cls], 1u);
+    // a prefilled frame (Params::prefilled) needs no painting: tiles that are not traced are not listed
+    const bool listed = in_band && (traced || P.prefilled == 0u);
+    if (listed) rank = atomicAdd(&n_cls[cls], 1u);
     __syncthreads();
     if (threadIdx.x <= kCostClasses) base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[P.qsel * 16u + threadIdx.x], n_cls[threadIdx.x]) : 0u;
     __syncthreads();
-    if (in_band) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (no_cubes ? kEntryNoCubes : 0u) | (by << 16);
+    if (listed) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (no_cubes ? kEntryNoCubes : 0u) | (by << 16);
+    // ... except for the reference's never-painted pixel i == width (render.rs:316-322; row 1, column 0): it is 0
+    // whether its tile is traced (the render kernel writes 0 there too) or sky
+    if (P.prefilled != 0u && t == 0u && P.part == 0u && P.y0 <= 1u && 1u < P.y1 && P.out) P.out[(size_t)(1u - P.y0) * P.width] = 0u;
 }
 
 // render_kernel: single-wave workgroups, one lane per pixel of an 8x8 tile (coherent rays give tight

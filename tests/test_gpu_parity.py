@@ -115,6 +115,7 @@ def test_interleaved_parts_reassemble(gpu_ctx, default_scene):
         for p in range(n):
             rows = multigpu.part_rows(h, n, p)
             buf = torch.zeros((multigpu.max_part_rows(h, n), w), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()  # torch's fill is not ordered against the library's stream
             gpu_ctx.render_device(f, buf.data_ptr(), n_parts=n, part=p)
             gpu_ctx.sync()
             frame[multigpu.part_row_indices(h, n, p)] = buf[:rows].cpu().numpy().view(np.uint32)
@@ -183,6 +184,7 @@ def test_frame_pipeline_on_one_gpu(gpu_ctx, default_scene):
     ctx2.upload(default_scene)
     ctxs = [gpu_ctx, ctx2]
     streams = [ext, torch.cuda.ExternalStream(ctx2.stream(), device=dev)]
+    torch.cuda.synchronize()  # the buffers' zero fills ran on the first context's stream only
     pipe = multigpu.FramePipeline(fg, lambda buf, slot: ctxs[slot].render_device(f, buf.data_ptr()), streams)
     cams, got = [], []
     cam = default_scene.camera

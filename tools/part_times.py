@@ -22,6 +22,7 @@ f = scene.frame(W, H)
 out = {}
 for n in (1, 2, 4, 8):
     buf = torch.zeros((multigpu.max_part_rows(H, n), W), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     rows = []
     for p in range(n):
         for _ in range(3):
