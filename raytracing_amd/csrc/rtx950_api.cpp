@@ -67,7 +67,6 @@ struct rt_ctx {
     uint32_t* d_cost = nullptr;
     size_t cost_cap = 0;
     uint32_t launch_seq = 0;   // selects the queue header bank
-    bool prefill = true;              // RTX950_PREFILL=0: paint sky tiles inside the render kernel instead
     uint32_t max_workgroups = 24576;  // grid of render_kernel: 6x the resident single-wave workgroups of an MI355X (swept: 12K..32K within 3 %)
     // timing
     bool timing = false;
@@ -394,7 +393,6 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
         delete c;
         return fail_hip(nullptr, e, "hipMalloc(counters)");
     }
-    if (const char* g = getenv("RTX950_PREFILL")) c->prefill = atoi(g) != 0;  // tuning experiments
     if (const char* g = getenv("RTX950_GRID")) { long v = atol(g); if (v > 0 && v < (1l << 30)) c->max_workgroups = (uint32_t)v; }  // tuning experiments
     *out_ctx = c;
     return RT_OK;
@@ -766,10 +764,11 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
         p.tree_hash = dbg_device->tree_hash;
         variant = kVariantDebug;
     }
-    if (variant == kVariantRender && ctx->prefill) {
+    if (variant == kVariantRender) {
         // Three quarters of a typical frame are sky: a fill ahead of the launches (a kernel of the runtime,
         // 33 MB at 4K in about 10 us - under the previous frame's render kernel when the host keeps two frames
-        // in flight) writes them instead of 16-tile paint groups at the end of the render kernel.
+        // in flight) writes them instead of 16-tile paint groups at the end of the render kernel (whose plain
+        // variant has no painting code: the variants with debug planes or counters still paint and count).
         const size_t npx = (size_t)rt_part_rows(frame->y1 - frame->y0, n_parts, part) * frame->width;
         if (npx) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_out_0rgb, (int)p.sky, npx, ctx->stream));
         p.prefilled = 1u;

@@ -1475,6 +1475,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
         if (!found) {
             // The traced tiles are all handed out: this workgroup paints kPaintGroup of the others (sky
             // colour, "no hit" planes) and counts the rays the reference would still have cast for them.
+            // plain frames are prefilled with the sky colour (rt_render_device_part) and list no paint-only tiles: no
+            // traced tile left means done; the variants with debug planes or counters paint and count here
+            if constexpr (!DBG && !COUNT) break;
             KCONST uint32_t* sky_list = q + kQueueBase + kCostClasses * tiles;
             const uint32_t n_sky = q[P.qsel * 16u + kCostClasses];
             if (idx * kPaintGroup >= n_sky) break;  // no items left (every wave gets here: items only grow)
