@@ -8,8 +8,9 @@ the gather of those buffers to rank 0, which scatters the rows back into frame o
 Two things keep that exchange off the critical path:
   * only the rows that can hold geometry travel (rt_frame_row_extent, a host-side bound every rank
     computes identically): rank 0 fills the other rows with the sky colour itself;
-  * FramePipeline renders frame f+1 while frame f is being gathered (two message buffers, the gather
-    on its own stream).
+  * FramePipeline keeps two frames in flight per rank (two message buffers, two library contexts, each
+    frame's render, gather and scatter in order on its slot's stream): frame f+1 renders while frame f
+    is gathered.
 The functions here are backend-agnostic (RCCL on GPUs, gloo in the CPU tests).
 """
 import numpy as np
