@@ -3,6 +3,8 @@
 Bar (BASELINE.json north_star): hit indices bit-exact; 8-bit colour within 1 LSB per channel on
 >= 99.9% of pixels.  The oracle is "parity unpinned" except for Color*f32 (see oracle/rt_oracle.c).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -390,3 +392,41 @@ def test_random_scenes(gpu_ctx, oracle_mod, default_scene, seed):
     f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, 96, 64)
     assert_parity(gfb, gpl, ofb, opl, label)
     assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+
+
+def test_rccl_gather_on_the_library_stream(gpu_ctx, default_scene):
+    """The collective of the N-GPU path as RCCL sees it, at world size 1 (one GPU here): dist.gather called
+    with the context's stream current, receiving into the views FrameGather hands it, ordered behind the
+    render on that stream with no host wait in between."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import multigpu
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        gpu_ctx.upload(default_scene)
+        w, h = 200, 120
+        f = default_scene.frame(w, h)
+        ext = torch.cuda.ExternalStream(gpu_ctx.stream(), device=dev)
+        with torch.cuda.stream(ext):
+            fg = multigpu.FrameGather(h, w, 1, 0, dev, depth=1)
+            recv = torch.zeros((1, fg.max_rows, w), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        y0, y1 = gpu_ctx.row_extent(f)
+        a, b, fa, fb = multigpu.message_window(h, 1, (y0, y1))
+        gpu_ctx.render_device(f, fg.local.data_ptr())
+        with torch.cuda.stream(ext):
+            dist.gather(fg.local[a:b], [recv[0, : b - a]], dst=0)
+        ext.synchronize()
+        want = gpu_ctx.render(f)
+        got = recv[0, : b - a].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want[a:b])
+    finally:
+        dist.destroy_process_group()
