@@ -8,7 +8,7 @@ frame's 16-row blocks are dealt round-robin to the ranks (strong scaling, total 
 rank's compact band (the rows that can hold geometry) is gathered to GPU0 over RCCL/xGMI inside the
 timed region, overlapped with the rendering of the next frame.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 400 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -114,14 +114,19 @@ def cpu_baseline(scene, width, height, target_s, max_threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400,
+                    help="timed frames; the default is long enough for the GPU's clocks to settle (20 frames are over in 4 ms and "
+                         "measure 8 %% slower)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="minecraft_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU baseline sample; 0 disables it")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (one library context and stream each: the next frame starts under the current "
                          "frame's slowest tiles); 0 = the default of 2 at every N; 1 = strictly one frame at a time")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="bracket every k-th launch of the render kernel with HIP events (roofline.kernel_avg_ms); the two event "
+                         "records cost the stream about 6 us per launch, so timing every launch slows the frame it measures by 4 %%")
     ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
     args = ap.parse_args()
 
@@ -173,9 +178,9 @@ def main():
     out = fg.local  # [max_part_rows, W] int32, padded so every rank sends the same size
     # N > 1: frame f+1 renders while frame f is gathered to GPU0 and while f's slowest tiles finish (a rank
     # holds 1/N of the work but the whole critical path); every frame is whole on GPU0 before the timed
-    # region ends (sync() below waits for all streams).  2 in flight by default: with RCCL's own stream and
-    # the null stream that is one hardware queue per stream (GPU_MAX_HW_QUEUES = 4)
-    # and so does its slowest tile: one library context (own stream, queue, tile costs) per message buffer
+    # region ends (sync() below waits for all streams).  One library context (own stream, tile queue, tile
+    # costs) per message buffer; 2 in flight by default: with RCCL's own stream and the null stream that is
+    # one hardware queue per stream (GPU_MAX_HW_QUEUES = 4), so no two of them serialise on a shared queue
     ctxs, streams = [ctx], [ext]
     if inflight > 1:
         for _ in range(len(fg.locals) - 1):
@@ -211,7 +216,7 @@ def main():
         step()
     sync()
     for c in ctxs:
-        c.enable_timing(True)
+        c.enable_timing(max(1, args.time_every))
         c.kernel_time_ms()  # drop anything recorded so far
     if world > 1:
         dist.barrier()
@@ -293,7 +298,7 @@ def main():
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic_from_profile(args.workload),
-                "kernel": "render_kernel<false,false>", "kernel_avg_ms": kern_ms, "launches_timed": kern_n, "launches_overlap": inflight > 1,
+                "kernel": "render_kernel<false,false>", "kernel_avg_ms": kern_ms, "launches_timed": kern_n, "timed_every": max(1, args.time_every), "launches_overlap": inflight > 1,
                 "algorithmic_flops_per_launch": flops_launch,
                 "frac_of_nonfma_lane_op_ceiling": achieved_tf / PEAK_LANE_OPS_T,
                 # executed view from the committed rocprofv3 PMC pass of this command (profiles/traffic.json)
@@ -316,7 +321,7 @@ def main():
             for _ in range(3):
                 ctx.render_device(frame, out.data_ptr())
             ctx.sync()
-            ctx.enable_timing(True)
+            ctx.enable_timing(max(1, args.time_every))
             ctx.kernel_time_ms()
             t1 = time.perf_counter()
             for _ in range(args.steps):

@@ -236,7 +236,9 @@ int rt_count_rays_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
  * (the reference shows fps in its window title, src/main.rs:122-131). */
 int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches);
 
-/* Toggle HIP-event timing of rt_render_device launches (off by default). */
+/* HIP-event timing of rt_render_device launches (off by default): enable = 0 off, 1 every launch,
+ * k > 1 every k-th launch (a pair of event records costs the stream about 6 us per launch, 4 % of the
+ * 4K frame: a sample keeps a live measurement from slowing what it measures). */
 int rt_enable_timing(rt_ctx* ctx, int enable);
 
 /* Diagnostic, no counterpart in the reference: runs about n_cases pseudo-random f32 divisions on the

@@ -205,7 +205,8 @@ class Context:
         return bad.value, n.value
 
     def enable_timing(self, on=True):
-        self._check(self._lib.rt_enable_timing(self._ctx, 1 if on else 0))
+        """False/0: off; True/1: every launch; k > 1: every k-th launch."""
+        self._check(self._lib.rt_enable_timing(self._ctx, int(on)))
 
     def kernel_time_ms(self):
         avg, n = C.c_double(), C.c_uint32()

@@ -70,6 +70,7 @@ struct rt_ctx {
     uint32_t max_workgroups = 24576;  // grid of render_kernel: 6x the resident single-wave workgroups of an MI355X (swept: 12K..32K within 3 %)
     // timing
     bool timing = false;
+    uint32_t timing_every = 1, timing_phase = 0;  // every k-th launch is bracketed by events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded pairs since last query
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
 };
@@ -346,7 +347,8 @@ int launch_timed(rt_ctx* ctx, const Params& p, int variant)
     if (rc != RT_OK) return rc;
     hipError_t e = hipSuccess;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    if (ctx->timing) {
+    const bool timed = ctx->timing && (ctx->timing_phase++ % ctx->timing_every == 0u);
+    if (timed) {
         if (!ctx->event_pool.empty()) {
             ev = ctx->event_pool.back();
             ctx->event_pool.pop_back();
@@ -358,7 +360,7 @@ int launch_timed(rt_ctx* ctx, const Params& p, int variant)
     }
     e = (hipError_t)launch_render(p, variant, (void*)ctx->stream, ctx->max_workgroups);
     if (e != hipSuccess) return fail_hip(ctx, e, "render kernel launch");
-    if (ctx->timing) {
+    if (timed) {
         HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
         ctx->events.push_back(ev);
     }
@@ -765,13 +767,18 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
         variant = kVariantDebug;
     }
     if (variant == kVariantRender) {
-        // Three quarters of a typical frame are sky: a fill ahead of the launches (a kernel of the runtime,
-        // 33 MB at 4K in about 10 us - under the previous frame's render kernel when the host keeps two frames
-        // in flight) writes them instead of 16-tile paint groups at the end of the render kernel (whose plain
-        // variant has no painting code: the variants with debug planes or counters still paint and count).
+        // Three quarters of a typical frame are sky.  Those tiles are painted by build_queue, which has just
+        // found that they need no tracing (16-byte stores: 25 MB of the 4K frame in 3 us), instead of 16-tile
+        // paint groups at the end of the render kernel (whose plain variant has no painting code: the variants
+        // with debug planes or counters still paint and count).  A buffer or width that 16-byte stores do not
+        // fit is filled by the runtime ahead of the launches instead (33 MB at 4K in 20 us).
         const size_t npx = (size_t)rt_part_rows(frame->y1 - frame->y0, n_parts, part) * frame->width;
-        if (npx) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_out_0rgb, (int)p.sky, npx, ctx->stream));
-        p.prefilled = 1u;
+        if (((uintptr_t)d_out_0rgb & 15u) == 0u && (frame->width & 3u) == 0u && getenv("RTX950_FILL_MEMSET") == nullptr) {
+            p.prefilled = 2u;  // build_queue paints the tiles it does not list (16-byte stores)
+        } else {
+            if (npx) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_out_0rgb, (int)p.sky, npx, ctx->stream));
+            p.prefilled = 1u;
+        }
     }
     return launch_timed(ctx, p, variant);
 }
@@ -873,7 +880,10 @@ int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t*
 int rt_enable_timing(rt_ctx* ctx, int enable)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
+    if (enable < 0) return fail(ctx, RT_ERR_INVALID_ARG, "enable must be 0 (off), 1 (every launch) or k > 1 (every k-th launch)");
     ctx->timing = enable != 0;
+    ctx->timing_every = enable > 1 ? (uint32_t)enable : 1u;
+    ctx->timing_phase = 0u;
     return RT_OK;
 }
 

@@ -136,9 +136,11 @@ struct Params {
     uint32_t* hit_sphere;
     uint32_t* tree_hash;
     unsigned long long* counters;  // 10 x u64, rt_counters order
-    // 1: `out` holds the sky colour everywhere already (a fill ahead of the launches): build_queue lists no
-    // tile that is only painted, so the render kernel has no paint groups.  (Last member on purpose: the
-    // render kernel does not read it, and its code stays the same to the instruction.)
+    // 0: build_queue lists the tiles that are only painted and the render kernel paints them (variants with
+    // debug planes or counters).  1: `out` holds the sky colour everywhere already (a fill ahead of the
+    // launches); 2: build_queue paints those tiles itself; in both cases it lists none of them, so the
+    // render kernel has no paint groups.  (Last member on purpose: the render kernel does not read it, and
+    // its code stays the same to the instruction.)
     uint32_t prefilled;
 };
 

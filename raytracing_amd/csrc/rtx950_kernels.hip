@@ -53,6 +53,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 // NB: never apply __builtin_bit_cast directly to a vector element (`bit_cast(float, v[k])`): hipcc
 // (ROCm 7.2) then reads element 0 for every k.  Copy the element to a scalar first.
@@ -1430,7 +1431,32 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
     if (listed) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (no_cubes ? kEntryNoCubes : 0u) | (by << 16);
     // ... except for the reference's never-painted pixel i == width (render.rs:316-322; row 1, column 0): it is 0
     // whether its tile is traced (the render kernel writes 0 there too) or sky
-    if (P.prefilled != 0u && t == 0u && P.part == 0u && P.y0 <= 1u && 1u < P.y1 && P.out) P.out[(size_t)(1u - P.y0) * P.width] = 0u;
+    if (P.prefilled == 1u && t == 0u && P.part == 0u && P.y0 <= 1u && 1u < P.y1 && P.out) P.out[(size_t)(1u - P.y0) * P.width] = 0u;
+    // prefilled == 2: this kernel is the fill.  The block paints the tiles it has just found to need no
+    // tracing: thread j takes half a tile row (4 pixels, one 16-byte store), so a wave writes 1 KB of
+    // consecutive addresses per pixel row wherever the tiles are consecutive; disjoint from every pixel
+    // the render kernel writes.  (The host chooses this only for a 16-byte aligned buffer and width % 4 == 0.)
+    if (P.prefilled == 2u) {
+        __shared__ uint8_t paint[1024];
+        paint[threadIdx.x] = (in_band && !traced) ? 1u : 0u;
+        __syncthreads();
+        const uint32_t t0 = blockIdx.x * 1024u;
+        for (uint32_t j = threadIdx.x; j < 2048u; j += 1024u) {
+            const uint32_t lt = j >> 1;
+            if (paint[lt] == 0u) continue;
+            const uint32_t tt = t0 + lt;
+            const uint32_t pbx = tt % P.grid_tx, pby = tt / P.grid_tx;
+            const uint32_t x = pbx * 8u + (j & 1u) * 4u;
+            if (x >= P.width) continue;
+            const uint32_t fy0 = tile_y0(P, pby);
+            uint32_t* row = P.out + (size_t)(pby * 8u) * P.width + x;
+            for (uint32_t r = 0; r < 8u && fy0 + r < P.y1; ++r) {
+                u32x4 v = {P.sky, P.sky, P.sky, P.sky};
+                if (fy0 + r == 1u && x == 0u) v[0] = 0u;  // the never-painted pixel i == width
+                *(u32x4*)(row + (size_t)r * P.width) = v;
+            }
+        }
+    }
 }
 
 // render_kernel: single-wave workgroups, one lane per pixel of an 8x8 tile (coherent rays give tight

@@ -430,3 +430,36 @@ def test_rccl_gather_on_the_library_stream(gpu_ctx, default_scene):
         assert np.array_equal(got, want[a:b])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h,y0,y1", [(328, 200, 0, None), (1080, 720, 0, None), (328, 200, 1, 77), (328, 200, 2, 200), (36, 9, 0, None), (8, 2, 0, None)])
+def test_fill_paths_agree(gpu_ctx, default_scene, w, h, y0, y1):
+    """Sky tiles painted by build_queue (16-byte stores; aligned buffer, width % 4 == 0) == the runtime's
+    fill ahead of the launches (RTX950_FILL_MEMSET forces it) == a buffer the stores do not fit (offset by
+    one pixel), for whole frames, bands and the parts of a 3-rank job."""
+    import torch
+    gpu_ctx.upload(default_scene)
+    f = default_scene.frame(w, h, y0=y0, y1=y1)
+    rows = f.y1 - f.y0
+    dev = torch.device("cuda", 0)
+    for n_parts, part in ((1, 0), (3, 0), (3, 2)):
+        bufs = []
+        for mode in ("paint", "memset", "misaligned"):
+            raw = torch.full((rows * w + 8,), 0x55AA55, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            off = 1 if mode == "misaligned" else 0
+            if mode == "memset":
+                os.environ["RTX950_FILL_MEMSET"] = "1"
+            try:
+                gpu_ctx.render_device(f, raw.data_ptr() + 4 * off, n_parts=n_parts, part=part)
+                gpu_ctx.sync()
+            finally:
+                os.environ.pop("RTX950_FILL_MEMSET", None)
+            got = raw.cpu().numpy()
+            assert (got[:off] == 0x55AA55).all()
+            bufs.append(got[off:])
+        from raytracing_amd import multigpu
+        n = multigpu.part_rows(rows, n_parts, part) * w
+        assert np.array_equal(bufs[0][:n], bufs[1][:n]) and np.array_equal(bufs[0][:n], bufs[2][:n]), (n_parts, part)
+        # nothing is written past the part's rows
+        assert (bufs[0][n:] == 0x55AA55).all() and (bufs[1][n:] == 0x55AA55).all() and (bufs[2][n:n + 7] == 0x55AA55).all()

@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH_ARGS="--steps 10 --warmup 2 --cpu-seconds 0 $*"
+BENCH_ARGS="--cpu-seconds 0 $*"  # bench.py's default steps and warmup: the traced command is the measured one
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 echo "trace done"
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \

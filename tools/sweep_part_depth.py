@@ -1,0 +1,40 @@
+"""What one rank of an N-GPU job can do by itself (no collective): its part of the 4K frame rendered
+back-to-back with 1, 2 or 3 frames in flight.  Prints ms per frame, slowest part of each N.
+Usage: python tools/sweep_part_depth.py [workload]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import raytracing_amd as rt  # noqa: E402
+import bench  # noqa: E402
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "minecraft_4k"
+kind, kwargs, W, H = bench.WORKLOADS[workload]
+scene = bench.make_scene(rt, kind, kwargs)
+frame = scene.frame(W, H)
+dev = torch.device("cuda", 0)
+ctxs = [rt.Context(0) for _ in range(3)]
+for c in ctxs:
+    c.upload(scene)
+bufs = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in ctxs]
+torch.cuda.synchronize()
+frames = 200
+for n in (1, 2, 4, 8):
+    for depth in (1, 2, 3):
+        worst = 0.0
+        for part in range(n):
+            for rep in range(2):  # the first repetition settles the tile costs
+                for c in ctxs:
+                    c.sync()
+                t0 = time.perf_counter()
+                for f in range(frames):
+                    s = f % depth
+                    ctxs[s].render_device(frame, bufs[s].data_ptr(), n_parts=n, part=part)
+                for c in ctxs:
+                    c.sync()
+                ms = (time.perf_counter() - t0) / frames * 1e3
+            worst = max(worst, ms)
+        print(f"{workload} N={n} frames_in_flight={depth}: slowest part {worst:.4f} ms/frame", flush=True)
