@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket every k-th launch of the render kernel with HIP events (roofline.kernel_avg_ms); the two event "
                          "records cost the stream about 6 us per launch, so timing every launch slows the frame it measures by 4 %%")
+    ap.add_argument("--grid-limit", type=int, default=-1,
+                    help="rt_set_grid_limit of every context; -1 = 12288 with frames in flight (two render kernels share the GPU), "
+                         "the library's default (24576) with one")
     ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
     args = ap.parse_args()
 
@@ -188,6 +191,9 @@ def main():
             c2.upload(scene)
             ctxs.append(c2)
             streams.append(torch.cuda.ExternalStream(c2.stream(), device=dev))
+    grid_limit = args.grid_limit if args.grid_limit >= 0 else (12288 if inflight > 1 else 0)
+    for c in ctxs:
+        c.set_grid_limit(grid_limit)
     pipe = FramePipeline(fg, lambda buf, slot: ctxs[slot].render_device(frame, buf.data_ptr(), n_parts=world, part=rank), streams) if piped else None
 
     orbit = bool(kwargs.get("orbit"))
@@ -308,6 +314,7 @@ def main():
             },
         }
         if pipe is not None or inflight > 1:
+            result["config"]["grid_limit"] = grid_limit if grid_limit > 0 else 24576
             result["config"]["frame_check"] = "gathered frame identical to the frame rendered whole on GPU0 (checked after the timed region)"
         if world == 1 and args.cpu_seconds > 0:
             cb = cpu_baseline(scene, W, H, args.cpu_seconds, args.cpu_threads)
@@ -318,6 +325,7 @@ def main():
             # frame takes from launch to completion, and the render kernel's duration alone on the GPU.
             if orbit:
                 frame.camera = scene.camera
+            ctx.set_grid_limit(0)  # the library's default, which is the best for one frame at a time
             for _ in range(3):
                 ctx.render_device(frame, out.data_ptr())
             ctx.sync()
@@ -330,6 +338,7 @@ def main():
             dt = (time.perf_counter() - t1) / args.steps
             solo_ms, _ = ctx.kernel_time_ms()
             ctx.enable_timing(False)
+            ctx.set_grid_limit(grid_limit)
             result["config"]["one_frame_in_flight"] = {"ms_per_step": dt * 1e3, "value": rays_uniq / dt / 1e6, "unit": "Mrays/s",
                                                        "kernel_avg_ms": solo_ms,
                                                        "roofline_frac": (flops_launch / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if solo_ms > 0 else None,

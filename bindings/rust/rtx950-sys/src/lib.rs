@@ -160,6 +160,7 @@ extern "C" {
     pub fn rt_count_rays_part(ctx: *mut rt_ctx, frame: *const rt_frame, n_parts: u32, part: u32, out: *mut rt_counters) -> c_int;
     pub fn rt_kernel_time_ms(ctx: *mut rt_ctx, out_avg_ms: *mut f64, out_launches: *mut u32) -> c_int;
     pub fn rt_enable_timing(ctx: *mut rt_ctx, enable: c_int) -> c_int;
+    pub fn rt_set_grid_limit(ctx: *mut rt_ctx, max_workgroups: u32) -> c_int;
     pub fn rt_selftest_division(ctx: *mut rt_ctx, seed: u32, n_cases: u64, out_mismatches: *mut u64, out_cases: *mut u64) -> c_int;
     pub fn rt_get_stream(ctx: *mut rt_ctx, out_hip_stream: *mut *mut c_void) -> c_int;
 }

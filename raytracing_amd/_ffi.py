@@ -134,6 +134,7 @@ ABI_SYMBOLS = {
     "rt_count_rays_part": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_uint32, C.c_uint32, C.POINTER(Counters)]),
     "rt_kernel_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "rt_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_grid_limit": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rt_selftest_division": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rt_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rt_frame_row_extent": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -208,6 +208,10 @@ class Context:
         """False/0: off; True/1: every launch; k > 1: every k-th launch."""
         self._check(self._lib.rt_enable_timing(self._ctx, int(on)))
 
+    def set_grid_limit(self, max_workgroups=0):
+        """Upper limit of the render kernel's grid; 0 restores the default (rt_set_grid_limit)."""
+        self._check(self._lib.rt_set_grid_limit(self._ctx, int(max_workgroups)))
+
     def kernel_time_ms(self):
         avg, n = C.c_double(), C.c_uint32()
         self._check(self._lib.rt_kernel_time_ms(self._ctx, C.byref(avg), C.byref(n)))

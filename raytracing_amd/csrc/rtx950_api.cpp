@@ -22,6 +22,8 @@
 
 using namespace rtx950;
 
+constexpr uint32_t kDefaultGrid = 24576;
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -67,7 +69,7 @@ struct rt_ctx {
     uint32_t* d_cost = nullptr;
     size_t cost_cap = 0;
     uint32_t launch_seq = 0;   // selects the queue header bank
-    uint32_t max_workgroups = 24576;  // grid of render_kernel: 6x the resident single-wave workgroups of an MI355X (swept: 12K..32K within 3 %)
+    uint32_t max_workgroups = kDefaultGrid;  // grid of render_kernel: 6x the resident single-wave workgroups of an MI355X (swept: 12K..32K within 3 %)
     // timing
     bool timing = false;
     uint32_t timing_every = 1, timing_phase = 0;  // every k-th launch is bracketed by events
@@ -884,6 +886,14 @@ int rt_enable_timing(rt_ctx* ctx, int enable)
     ctx->timing = enable != 0;
     ctx->timing_every = enable > 1 ? (uint32_t)enable : 1u;
     ctx->timing_phase = 0u;
+    return RT_OK;
+}
+
+int rt_set_grid_limit(rt_ctx* ctx, uint32_t max_workgroups)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
+    if (max_workgroups >= (1u << 30)) return fail(ctx, RT_ERR_INVALID_ARG, "grid limit out of range");
+    ctx->max_workgroups = max_workgroups ? max_workgroups : kDefaultGrid;
     return RT_OK;
 }
 

@@ -1,6 +1,6 @@
 """What one rank of an N-GPU job can do by itself (no collective): its part of the 4K frame rendered
 back-to-back with 1, 2 or 3 frames in flight.  Prints ms per frame, slowest part of each N.
-Usage: python tools/sweep_part_depth.py [workload]"""
+Usage: python tools/sweep_part_depth.py [workload] [grid limit with frames in flight, 0 = library default]"""
 import os
 import sys
 import time
@@ -12,6 +12,7 @@ import raytracing_amd as rt  # noqa: E402
 import bench  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "minecraft_4k"
+limit = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 kind, kwargs, W, H = bench.WORKLOADS[workload]
 scene = bench.make_scene(rt, kind, kwargs)
 frame = scene.frame(W, H)
@@ -25,6 +26,8 @@ frames = 200
 for n in (1, 2, 4, 8):
     for depth in (1, 2, 3):
         worst = 0.0
+        for c in ctxs:
+            c.set_grid_limit(limit if depth > 1 else 0)
         for part in range(n):
             for rep in range(2):  # the first repetition settles the tile costs
                 for c in ctxs:
@@ -37,4 +40,4 @@ for n in (1, 2, 4, 8):
                     c.sync()
                 ms = (time.perf_counter() - t0) / frames * 1e3
             worst = max(worst, ms)
-        print(f"{workload} N={n} frames_in_flight={depth}: slowest part {worst:.4f} ms/frame", flush=True)
+        print(f"{workload} grid_limit={limit if depth > 1 else 0} N={n} frames_in_flight={depth}: slowest part {worst:.4f} ms/frame", flush=True)
