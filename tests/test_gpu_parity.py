@@ -463,3 +463,25 @@ def test_fill_paths_agree(gpu_ctx, default_scene, w, h, y0, y1):
         assert np.array_equal(bufs[0][:n], bufs[1][:n]) and np.array_equal(bufs[0][:n], bufs[2][:n]), (n_parts, part)
         # nothing is written past the part's rows
         assert (bufs[0][n:] == 0x55AA55).all() and (bufs[1][n:] == 0x55AA55).all() and (bufs[2][n:n + 7] == 0x55AA55).all()
+
+
+def test_grid_limit_changes_no_pixel(gpu_ctx, default_scene):
+    """rt_set_grid_limit is a tuning knob: any limit (one workgroup striding over the whole queue included)
+    renders the same frame and the same counters; 0 restores the default; absurd limits are refused."""
+    gpu_ctx.upload(default_scene)
+    f = default_scene.frame(328, 200)
+    want, want_planes = gpu_ctx.render(f, debug=True)
+    want_cnt = gpu_ctx.count_rays(f).uniq_dict()
+    try:
+        for limit in (1, 7, 64, 12288, 0):
+            gpu_ctx.set_grid_limit(limit)
+            got, planes = gpu_ctx.render(f, debug=True)
+            assert np.array_equal(got, want), limit
+            for k in want_planes:
+                assert np.array_equal(planes[k], want_planes[k]), (limit, k)
+            assert np.array_equal(gpu_ctx.render(f), want), limit
+            assert gpu_ctx.count_rays(f).uniq_dict() == want_cnt, limit
+        with pytest.raises(rt.RtError):
+            gpu_ctx.set_grid_limit(1 << 30)
+    finally:
+        gpu_ctx.set_grid_limit(0)
