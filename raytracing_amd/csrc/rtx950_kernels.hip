@@ -324,21 +324,28 @@ DEV bool cube_exact(const CubeRec& c, V3 o, V3 d, float& distance)
 // The distance of cube_exact for a cube that is known to pass the slab test, for a ray whose operands
 // are in the range of div_shared (div_ok: a "safe" ray, see ray_pre, without zero direction components:
 // |d_c| in [2^-40, 2^40], and every bound - o_c is 0 or of magnitude in [2^-53, 2^21], being a difference
-// of two floats that are 0 or in [2^-30, 2^20]).  Same six quotients, same staging; the two quotients of
-// an axis share one refined reciprocal.  Other lanes take cube_exact.
+// of two floats that are 0 or in [2^-30, 2^20]).  The same quotients in the same staging (three of the six
+// unless some lane needs tmax); the two quotients of an axis share one refined reciprocal.  Other lanes
+// take cube_exact.
 DEV float cube_distance(const CubeRec& c, V3 o, V3 d, bool div_ok)
 {
     const float rx = rcp_refined(d.x), ry = rcp_refined(d.y), rz = rcp_refined(d.z);
-    const float t0x = div_shared(c.minx - o.x, d.x, rx), t1x = div_shared(c.maxx - o.x, d.x, rx);
-    const float t0y = div_shared(c.miny - o.y, d.y, ry), t1y = div_shared(c.maxy - o.y, d.y, ry);
-    const float t0z = div_shared(c.minz - o.z, d.z, rz), t1z = div_shared(c.maxz - o.z, d.z, rz);
-    const bool sx = t0x < t1x, sy = t0y < t1y, sz = t0z < t1z;
-    float tmin = sx ? t0x : t1x, tmax = sx ? t1x : t0x;
-    tmin = __builtin_fmaxf(tmin, sy ? t0y : t1y);
-    tmax = __builtin_fminf(tmax, sy ? t1y : t0y);
-    tmin = __builtin_fmaxf(tmin, sz ? t0z : t1z);
-    tmax = __builtin_fminf(tmax, sz ? t1z : t0z);
-    float distance = (tmin < 0.0f) ? tmax : tmin;
+    // Per axis the reference's smaller quotient is the one whose numerator lies on the near side: for
+    // d > 0 the smaller numerator, for d < 0 the larger (division by d is monotone, and equal numerators
+    // give equal quotients, so which of two equal ones is taken changes no bit).  The three far quotients
+    // are only needed by rays that start inside the slab intersection (tmin < 0): wave-uniformly rare.
+    const float n0x = c.minx - o.x, n1x = c.maxx - o.x, n0y = c.miny - o.y, n1y = c.maxy - o.y, n0z = c.minz - o.z, n1z = c.maxz - o.z;
+    const bool lx = (n0x < n1x) == (d.x > 0.0f), ly = (n0y < n1y) == (d.y > 0.0f), lz = (n0z < n1z) == (d.z > 0.0f);
+    float tmin = div_shared(lx ? n0x : n1x, d.x, rx);
+    tmin = __builtin_fmaxf(tmin, div_shared(ly ? n0y : n1y, d.y, ry));
+    tmin = __builtin_fmaxf(tmin, div_shared(lz ? n0z : n1z, d.z, rz));
+    float distance = tmin;
+    if (__builtin_amdgcn_ballot_w64(tmin < 0.0f) != 0ull) {
+        float tmax = div_shared(lx ? n1x : n0x, d.x, rx);
+        tmax = __builtin_fminf(tmax, div_shared(ly ? n1y : n0y, d.y, ry));
+        tmax = __builtin_fminf(tmax, div_shared(lz ? n1z : n0z, d.z, rz));
+        distance = (tmin < 0.0f) ? tmax : tmin;
+    }
     if (__builtin_amdgcn_ballot_w64(!div_ok) != 0ull) {
         float e = 0.0f;
         (void)cube_exact(c, o, d, e);
