@@ -1264,7 +1264,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     const LightRec L = P.lights[li];
                     const V3 lp = v3(L.px, L.py, L.pz);
                     const V3 light_dir = vnormalize(vsub(lp, hit.p));
-                    const V3 reflect_dir = vnormalize(reflect(vneg(light_dir), hit.n));
+                    const V3 refl_raw = reflect(vneg(light_dir), hit.n);
                     uint32_t blocker;
                     PROF_MARK(PH_SHADE);
                     PROF_KIND(depth * 2u + 1u);
@@ -1273,12 +1273,26 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     const float light_intensity = L.intensity * (1.0f - shadow);
                     const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
                     const Col diffuse = col_mul(col_mul(tx_a, diffuse_intensity), light_intensity);
-                    const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m.specular);
-                    // (c * spec_i) truncates to 0 in every channel when spec_i < 1/256: the usual case away from
-                    // highlights, and then the specular term is exactly black
+                    // The specular term is trunc(trunc(trunc(c * albedo.1) * spec) * intensity) per channel with
+                    // c <= 255: exactly black when 255 * albedo.1 * spec < 1, the usual case away from highlights.
+                    // That can be seen before the reflection direction is normalised and the power taken:
+                    // reflect() of two unit vectors has length 1 (checked: within 1 %), so the cosine is at most
+                    // cb = the raw dot product + 0.6 % + 1e-5 (50x the rounding of either route), powf is monotone
+                    // in its base, and exp2(y log2 cb) is within 1e-3 of cb^y (see powf_like_libm).  NaNs fail
+                    // every compare and take the full route.
                     Col specular = Col{0.0f, 0.0f, 0.0f};
-                    if (wave_any(!(spec_i < 0x1p-8f)))
-                        specular = col_mul(col_mul(col_mul(col_from_hex(L.color_0rgb), m.albedo1), spec_i), light_intensity);
+                    const float rr = vdot(refl_raw, refl_raw);
+                    const float c_raw = vdot(view_dir, refl_raw);
+                    const float cb = c_raw + __builtin_fabsf(c_raw) * 0x1.8p-8f + 1e-5f;
+                    const float e_b = m.specular * __builtin_amdgcn_logf(cb);  // cb <= 0: NaN or -inf times y > 0
+                    const bool dark = (rr > 0.99f) && (rr < 1.01f) && (m.specular > 0.0f) &&
+                                      ((cb <= 0.0f) || ((cb < 1.0f) && (__builtin_amdgcn_exp2f(e_b) * (255.0f * m.albedo1) < 0.98f)));
+                    if (wave_any(hit_any && !dark)) {
+                        const V3 reflect_dir = vnormalize(refl_raw);
+                        const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m.specular);
+                        if (wave_any(!(spec_i < 0x1p-8f)))
+                            specular = col_mul(col_mul(col_mul(col_from_hex(L.color_0rgb), m.albedo1), spec_i), light_intensity);
+                    }
                     sum = col_add(sum, col_mul(col_add(diffuse, specular), k_ds));
                 }
                 PROF_MARK(PH_SHADE);

@@ -485,3 +485,30 @@ def test_grid_limit_changes_no_pixel(gpu_ctx, default_scene):
             gpu_ctx.set_grid_limit(1 << 30)
     finally:
         gpu_ctx.set_grid_limit(0)
+
+
+def test_specular_term_proved_black_early(gpu_ctx, oracle_mod, default_scene):
+    """The kernel skips the reflection normalisation and powf when 255 * albedo.1 * cos^specular < 1 can be
+    seen from the unnormalised reflection vector.  Materials and lights around that threshold: albedo.1
+    from 'always black' (255 a < 1) to far above 1, exponents below, at and above 1, zero, negative, huge
+    and NaN, dim and bright lights placed so that highlights fall on cube faces and on spheres."""
+    s = default_scene
+    V = rt.Vec3
+    base = list(s.materials)
+    combos = [(0.003, 1.0), (0.0039, 40.0), (0.05, 1.0), (0.05, 0.25), (1.0, 3.0), (8.0, 1.0), (0.5, 150.0), (0.05, 0.0),
+              (0.05, -2.0), (0.3, 1e30), (float("nan"), 2.0), (0.2, float("nan")), (-0.5, 2.0), (float("inf"), 5.0)]
+    mats = []
+    for k, (a1, sp) in enumerate(combos):
+        m = rt.Material.from_buffer_copy(base[k % len(base)])
+        m.albedo1, m.specular = a1, sp
+        m.reflectivity = 0.25 if k % 4 == 0 else 0.0
+        m.transparency = 0.0
+        mats.append(m)
+    cubes = [rt.Cube(k, V(-6.0 + 1.5 * (k % 8), -1.5 + 1.5 * (k // 8), 0.0), 1.5, k % len(mats)) for k in range(16)]
+    spheres = [rt.Sphere(100 + k, V(-5.0 + 2.5 * k, 2.5, 1.0), 0.9, (k + 3) % len(mats)) for k in range(5)]
+    lights = [rt.Light(V(0.5, 1.0, 9.0), 0xFFFFFF, 1.3), rt.Light(V(-7.0, 6.0, 4.0), 0x0A40FF, 0.8), rt.Light(V(6.0, -2.0, 7.0), 0x010203, 1.0)]
+    for eye in ((0.0, 0.5, 10.0), (7.0, 4.0, 6.0)):
+        sc = rt.make_scene(cubes, spheres, mats, lights, _cam(eye, (0.0, 0.0, 0.0)), s.ambient_light, s.sky_0rgb, s.atlas)
+        f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, 320, 200)
+        rep = assert_parity(gfb, gpl, ofb, opl, f"specular thresholds, eye {eye}")
+        assert rep["exact_fraction"] == 1.0, rep
