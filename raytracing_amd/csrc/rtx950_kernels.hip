@@ -1264,7 +1264,6 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     const LightRec L = P.lights[li];
                     const V3 lp = v3(L.px, L.py, L.pz);
                     const V3 light_dir = vnormalize(vsub(lp, hit.p));
-                    const V3 refl_raw = reflect(vneg(light_dir), hit.n);
                     uint32_t blocker;
                     PROF_MARK(PH_SHADE);
                     PROF_KIND(depth * 2u + 1u);
@@ -1281,6 +1280,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     // in its base, and exp2(y log2 cb) is within 1e-3 of cb^y (see powf_like_libm).  NaNs fail
                     // every compare and take the full route.
                     Col specular = Col{0.0f, 0.0f, 0.0f};
+                    const V3 refl_raw = reflect(vneg(light_dir), hit.n);
                     const float rr = vdot(refl_raw, refl_raw);
                     const float c_raw = vdot(view_dir, refl_raw);
                     const float cb = c_raw + __builtin_fabsf(c_raw) * 0x1.8p-8f + 1e-5f;
