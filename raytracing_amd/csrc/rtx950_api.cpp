@@ -715,6 +715,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.sphere_bound_max = sbmax;
     b.sphere_ok = sphere_ok ? 1u : 0u;
     b.mats = ctx->d_mats;
+    // a material whose direct light is exactly black (render kernel, trace_tree): anything not provably above
+    // the kernel's threshold selects the kernel variant that tests for it per lane
+    b.dark_materials = 0u;
+    for (size_t i = 0; i < n_materials; ++i)
+        if (!(1.0f - materials[i].reflectivity - materials[i].transparency >= 0.01f)) b.dark_materials = 1u;
+    if (getenv("RTX950_DARK_KERNEL")) b.dark_materials = atoi(getenv("RTX950_DARK_KERNEL")) ? 1u : 0u;  // parity tests: either kernel for any scene
     b.atlas = ctx->d_atlas;
     b.n_cubes = (uint32_t)n_cubes;
     b.n_spheres = (uint32_t)n_spheres;

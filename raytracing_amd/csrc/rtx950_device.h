@@ -142,6 +142,10 @@ struct Params {
     // render kernel has no paint groups.  (Last member on purpose: the render kernel does not read it, and
     // its code stays the same to the instruction.)
     uint32_t prefilled;
+    // 1: some material's direct light is exactly black (1 - reflectivity - transparency < 1/255, or not a
+    // number the host could bound): launch_render picks the kernel that tests for it per lane.  Host-side
+    // only, the kernels do not read it.
+    uint32_t dark_materials;
 };
 
 // classify_tiles: one wave per cube projects the cube's padded corners through the frame's camera and

@@ -1214,7 +1214,7 @@ DEV uint32_t node_finish(const Params& P, uint32_t sumf, float k_r, float k_t, u
 
 // One pass of render.rs:298-312 (spheres with ambient 1, or cubes with ambient_light) for the wave's
 // 64 primary rays: returns the packed colour, the primary hit index and the tree hash per lane.
-template <bool DBG, bool COUNT, bool LARGE>
+template <bool DBG, bool COUNT, bool LARGE, bool DARK>
 DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d, float ambient, uint32_t* stk, uint32_t& hash, uint32_t& hit_idx,
                         Totals& tot PROF_ARG)
 {
@@ -1259,15 +1259,26 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                 const V3 view_dir = vnormalize(vsub(o, hit.p));
                 const float k_ds = 1.0f - m.reflectivity - m.transparency;
 
+                // Direct light enters the colour as trunc(c * k_ds) per channel with c <= 255: exactly black for
+                // k_ds < 1/255 (water: 1 - 0.1 - 0.9), whatever the shadow rays find.  Such lanes cast none - the
+                // variants that report blockers or count rays still do - and a wave of them skips the loop.
+                // (DARK: compiled in only for scenes that hold such a material, rt_scene_upload decides; the
+                // other scenes' kernel does not carry the test.)
                 const uint32_t nl = P.n_lights;
-                for (uint32_t li = 0; li < nl; ++li) {
+                bool lit = hit_any;
+                uint32_t nl_cast = nl;
+                if constexpr (DARK && !DBG && !COUNT) {
+                    lit = hit_any && !(k_ds < 0.0039f);
+                    nl_cast = wave_any(lit) ? nl : 0u;
+                }
+                for (uint32_t li = 0; li < nl_cast; ++li) {
                     const LightRec L = P.lights[li];
                     const V3 lp = v3(L.px, L.py, L.pz);
                     const V3 light_dir = vnormalize(vsub(lp, hit.p));
                     uint32_t blocker;
                     PROF_MARK(PH_SHADE);
                     PROF_KIND(depth * 2u + 1u);
-                    const float shadow = shadow_query<COUNT, LARGE>(P, pass, hit_any, hit.p, lp, light_dir, hit.id, blocker, cnt PROF_PASS);
+                    const float shadow = shadow_query<COUNT, LARGE>(P, pass, lit, hit.p, lp, light_dir, hit.id, blocker, cnt PROF_PASS);
                     if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
                     const float light_intensity = L.intensity * (1.0f - shadow);
                     const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
@@ -1287,7 +1298,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     const float e_b = m.specular * __builtin_amdgcn_logf(cb);  // cb <= 0: NaN or -inf times y > 0
                     const bool dark = (rr > 0.99f) && (rr < 1.01f) && (m.specular > 0.0f) &&
                                       ((cb <= 0.0f) || ((cb < 1.0f) && (__builtin_amdgcn_exp2f(e_b) * (255.0f * m.albedo1) < 0.98f)));
-                    if (wave_any(hit_any && !dark)) {
+                    if (wave_any(lit && !dark)) {
                         const V3 reflect_dir = vnormalize(refl_raw);
                         const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m.specular);
                         if (wave_any(!(spec_i < 0x1p-8f)))
@@ -1490,7 +1501,7 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
 #ifndef RTX_WAVES_PER_EU
 #define RTX_WAVES_PER_EU 4
 #endif
-template <bool DBG, bool COUNT, bool LARGE>
+template <bool DBG, bool COUNT, bool LARGE, bool DARK = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PER_EU, RTX_WAVES_PER_EU))) void render_kernel(const Params P)
 {
     __shared__ uint32_t stk[kStackDepth * frame_words<DBG>() * 64];
@@ -1598,7 +1609,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
                     cnt.v[2] += tests; cnt.v[7] += tests;
                 }
             } else {
-                c = trace_tree<DBG, COUNT, LARGE>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
+                c = trace_tree<DBG, COUNT, LARGE, DARK>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
             }
             if (pass == PASS_SPHERES) { px = c; hs = hh; hit_s = hi; }
             else { px = (px == P.sky) ? c : px; hc = hh; hit_c = hi; }
@@ -1791,8 +1802,13 @@ int launch_render(const Params& p, int variant, void* stream, uint32_t max_workg
         else hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, 0, s, p);
         break;
     default:
-        if (large) hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, 0, s, p);
+        if (p.dark_materials != 0u) {
+            if (large) hipLaunchKernelGGL((render_kernel<false, false, true, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((render_kernel<false, false, false, true>), grid, block, 0, s, p);
+        } else {
+            if (large) hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, 0, s, p);
+        }
         break;
     }
     return (int)hipGetLastError();

@@ -512,3 +512,31 @@ def test_specular_term_proved_black_early(gpu_ctx, oracle_mod, default_scene):
         f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, 320, 200)
         rep = assert_parity(gfb, gpl, ofb, opl, f"specular thresholds, eye {eye}")
         assert rep["exact_fraction"] == 1.0, rep
+
+
+@pytest.mark.parametrize("force", ["0", "1"])
+def test_dark_material_kernel(gpu_ctx, oracle_mod, default_scene, water_scene, force, monkeypatch):
+    """Materials whose direct light is exactly black (1 - reflectivity - transparency < 1/255, e.g. the
+    reference's water) cast no shadow rays in the plain kernel's DARK variant, which rt_scene_upload picks
+    per scene; RTX950_DARK_KERNEL forces either variant for any scene.  k_ds around the threshold, zero,
+    negative, NaN; mixed tiles (dark and lit materials side by side); the plain frame must equal the
+    oracle and the debug variant's frame (which casts every shadow ray)."""
+    monkeypatch.setenv("RTX950_DARK_KERNEL", force)
+    s = default_scene
+    V = rt.Vec3
+    base = list(s.materials)
+    ks = [(0.1, 0.9), (0.5, 0.4962), (0.5, 0.4960), (0.3, 0.7), (0.6, 0.6), (float("nan"), 0.2), (0.0, 1.0), (0.0, 0.0), (0.25, 0.25)]
+    mats = []
+    for k, (r, t) in enumerate(ks):
+        m = rt.Material.from_buffer_copy(base[k % len(base)])
+        m.reflectivity, m.transparency = r, t
+        mats.append(m)
+    cubes = [rt.Cube(k, V(-5.25 + 1.5 * (k % 8), -0.75 + 1.5 * (k // 8), 0.0), 1.5, k % len(mats)) for k in range(24)]
+    spheres = [rt.Sphere(100 + k, V(-4.0 + 2.0 * k, 3.5, 1.5), 0.8, (2 * k) % len(mats)) for k in range(5)]
+    custom = rt.make_scene(cubes, spheres, mats, list(s.lights), _cam((1.0, 2.0, 11.0), (0.0, 0.5, 0.0)), s.ambient_light, s.sky_0rgb, s.atlas)
+    for name, sc in (("custom", custom), ("water", water_scene), ("default", s)):
+        f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, 240, 160)
+        rep = assert_parity(gfb, gpl, ofb, opl, f"dark-material kernel forced={force}, {name}")
+        assert rep["exact_fraction"] == 1.0, (name, rep)
+        assert np.array_equal(gpu_ctx.render(f), gfb), name  # plain variant == debug variant
+        assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
