@@ -2,8 +2,8 @@
 """bench.py — Mrays/s of the MI355X render path (BASELINE.json metric) on N GPUs of one node.
 
 A step = one frame of the workload rendered through the C-ABI (rt_render_device_part).  Two frames are
-in flight per GPU (two library contexts = two streams, frames alternate; --inflight), every frame
-complete before the timed region ends.  At N>1 the
+in flight on one GPU, three per rank of an N-GPU job (one library context = one stream each, frames
+alternate; --inflight), every frame complete before the timed region ends.  At N>1 the
 frame's 16-row blocks are dealt round-robin to the ranks (strong scaling, total work fixed) and each
 rank's compact band (the rows that can hold geometry) is gathered to GPU0 over RCCL/xGMI inside the
 timed region, overlapped with the rendering of the next frame.
@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (one library context and stream each: the next frame starts under the current "
-                         "frame's slowest tiles); 0 = the default of 2 at every N; 1 = strictly one frame at a time")
+                         "frame's slowest tiles); 0 = the default: 2 at N = 1, 3 per rank at N > 1; 1 = strictly one frame at a time")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket every k-th launch of the render kernel with HIP events (roofline.kernel_avg_ms); the two event "
                          "records cost the stream about 6 us per launch, so timing every launch slows the frame it measures by 4 %%")
@@ -174,7 +174,10 @@ def main():
     # the library's own stream as a torch stream: the gather of a frame is ordered after its render by events
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
     with torch.cuda.stream(ext):
-        inflight = args.inflight if args.inflight > 0 else 2
+        # default: 2 on one GPU (the frame is then bound by instruction issue); 3 per rank of an N-GPU job, whose
+        # 1/N of the frame is bound by its slowest tile (tools/sweep_part_depth.py with a stand-in for RCCL's
+        # stream: N = 4 and 8 gain 9-30 % over 2, N = 2 0-9 %, depending on how streams fall on hardware queues)
+        inflight = args.inflight if args.inflight > 0 else (2 if world == 1 else 3)
         piped = world > 1  # N = 1 renders straight into its frames: no message, no scatter
         fg = FrameGather(H, W, world, rank, dev, depth=inflight)
         outs = fg.locals  # N = 1: one whole frame per frame in flight ([max_part_rows, W] = [H, W] there)
@@ -182,8 +185,9 @@ def main():
     # N > 1: frame f+1 renders while frame f is gathered to GPU0 and while f's slowest tiles finish (a rank
     # holds 1/N of the work but the whole critical path); every frame is whole on GPU0 before the timed
     # region ends (sync() below waits for all streams).  One library context (own stream, tile queue, tile
-    # costs) per message buffer; 2 in flight by default: with RCCL's own stream and the null stream that is
-    # one hardware queue per stream (GPU_MAX_HW_QUEUES = 4), so no two of them serialise on a shared queue
+    # costs) per message buffer.  (GPU_MAX_HW_QUEUES = 4: with RCCL's stream and the null stream, 3 render
+    # streams mean that two streams share a hardware queue; measured with a stand-in for RCCL's stream, the
+    # third frame in flight still gains more than the sharing costs - see the default above.)
     ctxs, streams = [ctx], [ext]
     if inflight > 1:
         for _ in range(len(fg.locals) - 1):
