@@ -8,7 +8,7 @@ import sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "render_kernel<false, false" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 bench = json.load(open(sys.argv[2]))
-w, k = bench["warmup"], bench["steps"]
+w, k = bench["warmup"] + bench["config"].get("settle_frames", 0), bench["steps"]  # run-in + warm-up, timed
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 start = [int(r["Start_Timestamp"]) for r in rows]
 end = [int(r["End_Timestamp"]) for r in rows]
@@ -24,8 +24,8 @@ def region(name, a, b, events_ms):
     print(line)
 
 
-print(f"== render kernel by region of the traced run ({len(rows)} launches; warmup {w}, steps {k}, {bench['config'].get('frames_in_flight')} frame(s) in flight)")
-region("warm-up", 0, w, None)
+print(f"== render kernel by region of the traced run ({len(rows)} launches; run-in + warmup {w}, steps {k}, {bench['config'].get('frames_in_flight')} frame(s) in flight)")
+region("run-in + warm-up", 0, w, None)
 region("timed region", w, w + k, bench["roofline"]["kernel_avg_ms"])
 side = bench["config"].get("one_frame_in_flight")
 if side:
