@@ -1284,20 +1284,24 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
                     const Col diffuse = col_mul(col_mul(tx_a, diffuse_intensity), light_intensity);
                     // The specular term is trunc(trunc(trunc(c * albedo.1) * spec) * intensity) per channel with
-                    // c <= 255: exactly black when 255 * albedo.1 * spec < 1, the usual case away from highlights.
+                    // c <= c_max <= 255 (the light's brightest channel): exactly black when c_max * albedo.1 * spec < 1, the
+                    // usual case away from highlights.
                     // That can be seen before the reflection direction is normalised and the power taken:
                     // reflect() of two unit vectors has length 1 (checked: within 1 %), so the cosine is at most
                     // cb = the raw dot product + 0.6 % + 1e-5 (50x the rounding of either route), powf is monotone
                     // in its base, and exp2(y log2 cb) is within 1e-3 of cb^y (see powf_like_libm).  NaNs fail
                     // every compare and take the full route.
                     Col specular = Col{0.0f, 0.0f, 0.0f};
+                    const uint32_t lc = L.color_0rgb;  // wave-uniform: the light's brightest channel bounds c
+                    const uint32_t lc_rg = ((lc >> 16) & 0xFFu) > ((lc >> 8) & 0xFFu) ? ((lc >> 16) & 0xFFu) : ((lc >> 8) & 0xFFu);
+                    const float c_max = (float)(lc_rg > (lc & 0xFFu) ? lc_rg : (lc & 0xFFu));
                     const V3 refl_raw = reflect(vneg(light_dir), hit.n);
                     const float rr = vdot(refl_raw, refl_raw);
                     const float c_raw = vdot(view_dir, refl_raw);
                     const float cb = c_raw + __builtin_fabsf(c_raw) * 0x1.8p-8f + 1e-5f;
                     const float e_b = m.specular * __builtin_amdgcn_logf(cb);  // cb <= 0: NaN or -inf times y > 0
                     const bool dark = (rr > 0.99f) && (rr < 1.01f) && (m.specular > 0.0f) &&
-                                      ((cb <= 0.0f) || ((cb < 1.0f) && (__builtin_amdgcn_exp2f(e_b) * (255.0f * m.albedo1) < 0.98f)));
+                                      ((cb <= 0.0f) || ((cb < 1.0f) && (__builtin_amdgcn_exp2f(e_b) * (c_max * m.albedo1) < 0.98f)));
                     if (wave_any(lit && !dark)) {
                         const V3 reflect_dir = vnormalize(refl_raw);
                         const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m.specular);
