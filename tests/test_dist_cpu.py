@@ -65,11 +65,11 @@ def _extents(rows):
             (rows // 2, rows // 2), None, (2, rows - 1) if rows > 3 else (0, rows), (0, 1), (rows - 1, rows)]
 
 
-def _pipeline_worker(rank, world, port, rows, width, out_path):
+def _pipeline_worker(rank, world, port, rows, width, out_path, depth=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = multigpu.FrameGather(rows, width, world, rank, torch.device("cpu"), depth=2)
+    g = multigpu.FrameGather(rows, width, world, rank, torch.device("cpu"), depth=depth)
     idx = multigpu.part_row_indices(rows, world, rank)
     state = {}
 
@@ -91,10 +91,11 @@ def _pipeline_worker(rank, world, port, rows, width, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("rows,width,world", [(720, 16, 2), (45, 7, 2), (100, 5, 3), (16, 3, 1)])
-def test_pipeline_sends_only_the_extent(tmp_path, rows, width, world):
+@pytest.mark.parametrize("rows,width,world,depth", [(720, 16, 2, 2), (45, 7, 2, 3), (100, 5, 3, 3), (16, 3, 1, 2)])
+def test_pipeline_sends_only_the_extent(tmp_path, rows, width, world, depth):
+    """depth = frames in flight per rank: bench.py's default is 2 on one GPU and 3 per rank at N > 1."""
     out = str(tmp_path / "frames.npy")
-    mp.spawn(_pipeline_worker, args=(world, _free_port(), rows, width, out), nprocs=world, join=True)
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), rows, width, out, depth), nprocs=world, join=True)
     frames = np.load(out)
     for tag, extent in enumerate(_extents(rows)):
         assert np.array_equal(frames[tag], _image(rows, width, extent, tag)), (tag, extent)
