@@ -129,7 +129,7 @@ def main():
                          "records cost the stream about 6 us per launch, so timing every launch slows the frame it measures by 4 %%")
     ap.add_argument("--grid-limit", type=int, default=-1,
                     help="rt_set_grid_limit of every context; -1 = 12288 with frames in flight (two render kernels share the GPU), "
-                         "the library's default (24576) with one")
+                         "the library's default (32768) with one")
     ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
     args = ap.parse_args()
 
@@ -328,7 +328,7 @@ def main():
         }
         result["config"]["settle_frames"] = settle
         if pipe is not None or inflight > 1:
-            result["config"]["grid_limit"] = grid_limit if grid_limit > 0 else 24576
+            result["config"]["grid_limit"] = grid_limit if grid_limit > 0 else 32768
             result["config"]["frame_check"] = "gathered frame identical to the frame rendered whole on GPU0 (checked after the timed region)"
         if world == 1 and args.cpu_seconds > 0:
             cb = cpu_baseline(scene, W, H, args.cpu_seconds, args.cpu_threads)

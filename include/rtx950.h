@@ -242,7 +242,7 @@ int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches);
 int rt_enable_timing(rt_ctx* ctx, int enable);
 
 /* Tuning, no counterpart in the reference: upper limit of the render kernel's grid (single-wave workgroups
- * striding over the tile queue); 0 restores the default of 24576, the best for one frame at a time.  A
+ * striding over the tile queue); 0 restores the default of 32768, the best for one frame at a time.  A
  * host that keeps two frames in flight on two contexts gains from a smaller grid (12288: the 4K diorama
  * 3 % faster, the other benchmark frames within 2 % either way), because the two
  * frames' kernels then share the GPU from the start instead of queueing behind each other. */

@@ -22,7 +22,7 @@
 
 using namespace rtx950;
 
-constexpr uint32_t kDefaultGrid = 24576;
+constexpr uint32_t kDefaultGrid = 32768;  // swept at the end of round 1, one frame at a time: 24576 +2 %, 28672..49152 within 0.5 %, 65536 +1.5 %
 
 struct rt_ctx {
     int device = 0;
@@ -69,7 +69,7 @@ struct rt_ctx {
     uint32_t* d_cost = nullptr;
     size_t cost_cap = 0;
     uint32_t launch_seq = 0;   // selects the queue header bank
-    uint32_t max_workgroups = kDefaultGrid;  // grid of render_kernel: 6x the resident single-wave workgroups of an MI355X (swept: 12K..32K within 3 %)
+    uint32_t max_workgroups = kDefaultGrid;  // grid of render_kernel: 8x the resident single-wave workgroups of an MI355X
     // timing
     bool timing = false;
     uint32_t timing_every = 1, timing_phase = 0;  // every k-th launch is bracketed by events
