@@ -6,7 +6,14 @@
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTX950_ABI_VERSION: u32 = 1;
+pub const RTX950_ABI_VERSION: u32 = 2;
+pub const RT_EXEC_EVENTS: u32 = 12;
+pub const RT_NOALLOC_MAX_TILES: u32 = 131072;
+pub const RT_TUNE_COHERENT_SCALE: c_int = 1;
+pub const RT_TUNE_SHADOW_LIST: c_int = 2;
+pub const RT_TUNE_DARK_KERNEL: c_int = 3;
+pub const RT_TUNE_FILL_MEMSET: c_int = 4;
+pub const RT_TUNE_BVH_DEPTH_LIMIT: c_int = 5;
 pub const RT_MAX_DEPTH: u32 = 3; // src/render.rs:83
 pub const RT_MAX_LIGHTS: u32 = 16;
 pub const RT_TEXTURE_NONE: i32 = -1; // `texture: None`, src/material.rs:6
@@ -119,6 +126,24 @@ pub struct rt_counters {
     pub ref_shaded_hits: u64,
 }
 
+/// What the kernels execute for a band (`rt_count_executed`), per lane
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct rt_exec_counters {
+    pub cull_tests: u64,
+    pub chunk_tests: u64,
+    pub candidate_evals: u64,
+    pub exact_evals: u64,
+    pub bvh_steps: u64,
+    pub sphere_evals: u64,
+    pub queries: u64,
+    pub light_iterations: u64,
+    pub resolved_hits: u64,
+    pub blockers: u64,
+    pub child_setups: u64,
+    pub primary_rays: u64,
+}
+
 #[repr(C)]
 pub struct rt_ctx {
     _private: [u8; 0],
@@ -163,6 +188,21 @@ extern "C" {
     pub fn rt_set_grid_limit(ctx: *mut rt_ctx, max_workgroups: u32) -> c_int;
     pub fn rt_selftest_division(ctx: *mut rt_ctx, seed: u32, n_cases: u64, out_mismatches: *mut u64, out_cases: *mut u64) -> c_int;
     pub fn rt_get_stream(ctx: *mut rt_ctx, out_hip_stream: *mut *mut c_void) -> c_int;
+    pub fn rt_count_executed(ctx: *mut rt_ctx, frame: *const rt_frame, n_parts: u32, part: u32, out: *mut rt_counters, exec: *mut rt_exec_counters) -> c_int;
+    pub fn rt_set_tuning(ctx: *mut rt_ctx, key: c_int, value: f64) -> c_int;
+    pub fn rt_host_alloc(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
+    pub fn rt_host_free(ptr: *mut c_void) -> c_int;
+    pub fn rt_render_device_noalloc(ctx: *mut rt_ctx, frame: *const rt_frame, d_out_0rgb: *mut u32) -> c_int;
+    pub fn rt_render_multi(ctxs: *const *mut rt_ctx, n_ctx: u32, frame: *const rt_frame, d_frame_on_ctx0: *mut u32, out_bytes_moved: *mut u64) -> c_int;
+    pub fn rt_gather_bands(
+        ctxs: *const *mut rt_ctx,
+        n_ctx: u32,
+        d_parts: *const *const u32,
+        width: u32,
+        rows: u32,
+        d_band_on_ctx0: *mut u32,
+        out_bytes_moved: *mut u64,
+    ) -> c_int;
 }
 
 /// Error of a failed call: the status code and `rt_last_error`'s message.

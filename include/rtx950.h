@@ -18,6 +18,10 @@
  *   - colours are packed 0x00RRGGBB, exactly `From<Color> for u32` (reference src/color.rs:76-79).
  *   - a context is used by one host thread at a time; distinct contexts are independent
  *     (reference `render` needs `&mut Framebuffer`, so it is not re-entrant either).
+ *   - every call makes its context's GPU current for the duration of the call and restores the calling
+ *     thread's current HIP device before it returns.
+ *   - the library reads no environment variables; test and tuning knobs are explicit calls (rt_set_tuning,
+ *     rt_set_grid_limit).
  */
 #ifndef RTX950_H
 #define RTX950_H
@@ -29,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RTX950_ABI_VERSION 1u
+#define RTX950_ABI_VERSION 2u
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -150,13 +154,52 @@ typedef struct rt_counters {
     uint64_t ref_shaded_hits;
 } rt_counters;
 
+/* What the kernels EXECUTE for a band (rt_count_executed), per lane, as opposed to the reference's brute-force
+ * tests in rt_counters: the wave-level cull, the two-sided slab filter and the tile classification prove most
+ * of those tests away.  bench.py prices each event in FP32 operations ("Roofline") to state the
+ * kernel's executed arithmetic rate.  No reference counterpart. */
+typedef struct rt_exec_counters {
+    uint64_t cull_tests;        /* cube or sphere cull-stream records tested against a wave's ray bundle  */
+    uint64_t chunk_tests;       /* chunk bounding boxes tested against a wave's ray bundle (long lists)   */
+    uint64_t candidate_evals;   /* two-sided slab filter evaluations: (candidate cube, active ray) pairs  */
+    uint64_t exact_evals;       /* Cube::ray_intersect evaluated exactly for a pair the filter left open  */
+    uint64_t bvh_steps;         /* per-lane BVH walk steps (two sibling boxes each; long lists)           */
+    uint64_t sphere_evals;      /* Sphere::ray_intersect evaluations: (candidate sphere, active ray)      */
+    uint64_t queries;           /* per-ray query set-ups (nearest, exact re-run, shadow)                  */
+    uint64_t light_iterations;  /* (shaded hit, light) pairs of the Phong fold                            */
+    uint64_t resolved_hits;     /* winning hits resolved (exact distance, face, uv, material)             */
+    uint64_t blockers;          /* shadow blockers whose exact distance was computed                      */
+    uint64_t child_setups;      /* hits that set up reflection/refraction rays                            */
+    uint64_t primary_rays;      /* primary rays generated (pixels of traced tiles)                        */
+} rt_exec_counters;
+#define RT_EXEC_EVENTS 12u
+
+/* Largest frame, in 8x8 pixel tiles, that rt_render_device_noalloc accepts (4K = 129600 tiles). */
+#define RT_NOALLOC_MAX_TILES 131072u
+
+/* Keys of rt_set_tuning. */
+typedef enum rt_tuning {
+    RT_TUNE_COHERENT_SCALE = 1, /* factor on the long-list traversal threshold: 0 = every wave walks the BVH,
+                                   a huge value = every wave takes the chunk traversal; default 1.
+                                   Takes effect at the next rt_scene_upload                                */
+    RT_TUNE_SHADOW_LIST = 2,    /* -1 automatic (default), 0 / 1: shadow queries of long lists walk the
+                                   Morton-ordered / the list-ordered stream.  Next rt_scene_upload         */
+    RT_TUNE_DARK_KERNEL = 3,    /* -1 automatic (default), 0 / 1: kernel variant without / with the
+                                   "direct light is exactly black" test.  Next rt_scene_upload             */
+    RT_TUNE_FILL_MEMSET = 4,    /* 0 (default) / 1: sky pixels are written by a fill ahead of the launches
+                                   instead of by build_queue.  Next render call                            */
+    RT_TUNE_BVH_DEPTH_LIMIT = 5 /* deepest BVH the per-lane walk takes (1..28, default 28 = the walk's stack);
+                                   a deeper tree sends every wave through the chunk traversal.  28 levels
+                                   cannot be exceeded by a real list, so tests lower it.  Next rt_scene_upload */
+} rt_tuning;
+
 typedef struct rt_ctx rt_ctx;
 
 /* ABI / build identification.  No reference counterpart (library housekeeping). */
 uint32_t rt_abi_version(void);
 
 /* Create / destroy one context bound to HIP device `device` (one per GPU; owns a stream, the
- * device-resident scene, the device framebuffer and a pinned read-back buffer).
+ * device-resident scene, the device framebuffer rt_render copies from, and the launches' work buffers).
  * Replaces: construction of `Framebuffer::new` (reference src/framebuffer.rs:44-58) + `Model`
  * (src/main.rs:249-259) as far as device state is concerned. */
 int rt_ctx_create(int device, rt_ctx** out_ctx);
@@ -185,7 +228,9 @@ int rt_scene_upload(rt_ctx* ctx,
  * `framebuffer.buffer` layout, src/framebuffer.rs:15,105).  Reproduces the reference's unpainted
  * pixel i == width (src/render.rs:316-322 -> XTooLarge, src/framebuffer.rs:101-102), which keeps
  * the clear colour 0x000000 (src/framebuffer.rs:45,63-65).
- * `dbg_host` (nullable) receives the debug planes in host memory. */
+ * `dbg_host` (nullable) receives the debug planes in host memory.
+ * The single read-back is a DMA straight into `out_0rgb`: give it memory from rt_host_alloc (pinned) and the
+ * 4K frame's 33 MB arrive at PCIe rate; pageable memory works too, staged by the HIP runtime at a third of it. */
 int rt_render(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_0rgb,
               const rt_debug_planes* dbg_host);
 
@@ -220,6 +265,43 @@ uint32_t rt_part_rows(uint32_t rows, uint32_t n_parts, uint32_t part);
  * its pixel loop is reference src/render.rs:248-306). */
 int rt_frame_row_extent(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_y_first, uint32_t* out_y_end);
 
+/* Page-locked host memory for framebuffers that rt_render writes (`Framebuffer::new`, reference
+ * src/framebuffer.rs:44-58, allocates its `Vec<u32>` from the heap; the host mirror's Framebuffer uses
+ * this instead).  Usable with every context of the process. */
+int rt_host_alloc(size_t bytes, void** out_ptr);
+int rt_host_free(void* ptr);
+
+/* Allocation-free variant of rt_render_device, for callers that cannot call hipMalloc: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid allocation.  NO COUNTERPART in the reference.  Same
+ * kernels and same output as rt_render_device, but the launches' work buffers (tile stamps, tile queue, tile
+ * costs) live in one fixed array per GPU inside the library (5.8 MB, held until the process ends) instead of
+ * buffers the context allocates and grows; the call performs no hipMalloc/hipFree, creates no events and takes
+ * no timing samples.  Frames of more than RT_NOALLOC_MAX_TILES 8x8 tiles are refused with RT_ERR_LIMIT.  Every
+ * call on a GPU, from any context, shares that GPU's array: the array keeps the last call's contents (the
+ * call clears what must start at zero), and calls that overlap in time on one GPU race - wait for one
+ * (rt_sync) before issuing the next from another context. */
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out_0rgb);
+
+/* One frame on n GPUs, driven by one host thread (native counterpart of the RCCL gather in
+ * raytracing_amd/multigpu.py; pixel independence: reference src/render.rs:248-251,278-281).  ctxs[g] is a
+ * context on GPU g with the scene uploaded (several contexts may share a GPU); the rows of the band that can
+ * hold geometry (rt_frame_row_extent) are cut into 16-row blocks dealt round-robin to the contexts, each
+ * context renders its blocks into a buffer it owns, and the blocks are copied into frame order at
+ * `d_frame_on_ctx0` (device memory of ctxs[0]'s GPU, (y1-y0)*width u32) by peer copies over xGMI, one strided
+ * 2-D copy per context on that context's stream; ctxs[0] fills the sky rows itself.  Returns once everything
+ * is enqueued; rt_sync(ctxs[0]) waits for the whole frame.  `out_bytes_moved` (nullable): bytes that crossed
+ * between contexts.  The caller must not reuse `d_frame_on_ctx0` before the previous frame into it has been
+ * consumed (swap buffers or rt_sync). */
+int rt_render_multi(rt_ctx* const* ctxs, uint32_t n_ctx, const rt_frame* frame, uint32_t* d_frame_on_ctx0,
+                    uint64_t* out_bytes_moved);
+
+/* The gather step alone (SURVEY 8(b) `rt_gather_bands`): d_parts[g] is the compact output of
+ * rt_render_device_part(ctxs[g], .., n_ctx, g, ..) for a band of `rows` rows (device memory of ctxs[g]'s GPU,
+ * written on ctxs[g]'s stream); the parts are scattered into band order at `d_band_on_ctx0`.  Each copy is
+ * enqueued on its part's stream, ctxs[0]'s stream waits for all of them.  No reference counterpart. */
+int rt_gather_bands(rt_ctx* const* ctxs, uint32_t n_ctx, const uint32_t* const* d_parts, uint32_t width, uint32_t rows,
+                    uint32_t* d_band_on_ctx0, uint64_t* out_bytes_moved);
+
 /* Wait for all work enqueued on the context's stream.  No reference counterpart (the reference
  * is synchronous). */
 int rt_sync(rt_ctx* ctx);
@@ -230,6 +312,9 @@ int rt_sync(rt_ctx* ctx);
 int rt_count_rays(rt_ctx* ctx, const rt_frame* frame, rt_counters* out);
 /* Same, restricted to interleaved part `part` of `n_parts` (see rt_render_device_part). */
 int rt_count_rays_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, rt_counters* out);
+/* Same launch, also returning what the kernels executed (either pointer may be NULL). */
+int rt_count_executed(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, rt_counters* out,
+                      rt_exec_counters* exec);
 
 /* Average device time, in milliseconds, of the render kernel launches issued since the last call
  * (measured with HIP events on the context's stream), and their number.  No reference counterpart
@@ -247,6 +332,10 @@ int rt_enable_timing(rt_ctx* ctx, int enable);
  * 3 % faster, the other benchmark frames within 2 % either way), because the two
  * frames' kernels then share the GPU from the start instead of queueing behind each other. */
 int rt_set_grid_limit(rt_ctx* ctx, uint32_t max_workgroups);
+
+/* Test and tuning knobs, no counterpart in the reference (keys: rt_tuning).  The parity tests use them to
+ * force each traversal and kernel variant on any scene; results never depend on them. */
+int rt_set_tuning(rt_ctx* ctx, int key, double value);
 
 /* Diagnostic, no counterpart in the reference: runs about n_cases pseudo-random f32 divisions on the
  * device, once through the kernels' shared-reciprocal sequence and once through the compiler's IEEE

@@ -23,6 +23,13 @@ RT_MAX_DEPTH = 3
 RT_MAX_LIGHTS = 16
 RT_TEXTURE_NONE = -1
 RT_NO_HIT = 0xFFFFFFFF
+RT_EXEC_EVENTS = 12
+RT_NOALLOC_MAX_TILES = 131072
+RT_TUNE_COHERENT_SCALE = 1
+RT_TUNE_SHADOW_LIST = 2
+RT_TUNE_DARK_KERNEL = 3
+RT_TUNE_FILL_MEMSET = 4
+RT_TUNE_BVH_DEPTH_LIMIT = 5
 
 
 class Vec3(C.Structure):
@@ -114,6 +121,16 @@ class Counters(C.Structure):
         return int(self.nearest_rays + self.shadow_rays)
 
 
+class ExecCounters(C.Structure):
+    """rt_exec_counters: what the kernels executed (per lane), see include/rtx950.h."""
+    _fields_ = [(k, C.c_uint64) for k in (
+        "cull_tests", "chunk_tests", "candidate_evals", "exact_evals", "bvh_steps", "sphere_evals", "queries",
+        "light_iterations", "resolved_hits", "blockers", "child_setups", "primary_rays")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 # every symbol include/rtx950.h declares: name -> (restype, argtypes)
 ABI_SYMBOLS = {
     "rt_abi_version": (C.c_uint32, []),
@@ -138,6 +155,14 @@ ABI_SYMBOLS = {
     "rt_selftest_division": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rt_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rt_frame_row_extent": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_count_executed": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_uint32, C.c_uint32, C.POINTER(Counters), C.POINTER(ExecCounters)]),
+    "rt_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "rt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rt_host_free": (C.c_int, [C.c_void_p]),
+    "rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_void_p]),
+    "rt_render_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(Frame), C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rt_gather_bands": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p,
+                                  C.POINTER(C.c_uint64)]),
 }
 
 HOST_SYMBOLS = {
@@ -151,7 +176,7 @@ HOST_SYMBOLS = {
         [C.c_void_p, C.POINTER(Cube), C.POINTER(Sphere), C.POINTER(Material), C.POINTER(Light), C.POINTER(Camera),
          C.POINTER(C.c_float), C.POINTER(C.c_uint32)],
     ),
-    "rth_model_atlas": (C.c_int, [C.c_void_p, C.c_void_p] + [C.POINTER(C.c_uint32)] * 3),
+    "rth_model_atlas": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 4),
     "rth_model_update": (C.c_int, [C.c_void_p, C.c_int] + [C.c_float] * 5),
     "rth_render": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rth_bmp_encode": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]),

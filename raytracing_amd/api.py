@@ -10,8 +10,8 @@ from typing import Optional
 import numpy as np
 
 from . import _ffi
-from ._ffi import (Camera, Counters, Cube, DebugPlanes, Frame, Light, Material, Sphere, Vec3, RT_MAX_DEPTH, RT_NO_HIT,
-                   RT_OK)
+from ._ffi import (Camera, Counters, Cube, DebugPlanes, ExecCounters, Frame, Light, Material, Sphere, Vec3, RT_MAX_DEPTH,
+                   RT_NO_HIT, RT_OK)
 
 DAY_COLOR = 0x87CEEB  # reference src/render.rs:231
 NIGHT_COLOR = 0x030305  # reference src/render.rs:232
@@ -41,6 +41,16 @@ class Scene:
     sprite: int = 16
     name: str = "scene"
     _model: Optional[int] = field(default=None, repr=False)
+    _owns_model: bool = field(default=False, repr=False)
+
+    def __del__(self):
+        # the C++ host model behind a scene built by default_scene()/synthetic_scene()
+        m, self._model = getattr(self, "_model", None), None
+        if m and getattr(self, "_owns_model", False):
+            try:
+                _ffi.host().rth_model_free(m)
+            except Exception:
+                pass
 
     @property
     def n_cubes(self):
@@ -72,7 +82,8 @@ def make_scene(cubes, spheres, materials, lights, camera, ambient_light, sky_0rg
                  atlas.shape[1], sprite, name)
 
 
-def _scene_from_model(h, handle, name):
+def _scene_from_model(h, handle, name, own=False):
+    """Lower a host model to a Scene; own=True hands the model to the Scene (freed with it)."""
     n = [C.c_uint32() for _ in range(4)]
     if h.rth_model_counts(handle, *[C.byref(x) for x in n]) != 0:
         raise RuntimeError(h.rth_last_error().decode())
@@ -83,10 +94,15 @@ def _scene_from_model(h, handle, name):
     if h.rth_model_lower(handle, cubes, spheres, mats, lights, C.byref(cam), C.byref(amb), C.byref(sky)) != 0:
         raise RuntimeError(h.rth_model_lower.__name__ + ": " + h.rth_last_error().decode())
     tw, th, sp = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    h.rth_model_atlas(handle, None, C.byref(tw), C.byref(th), C.byref(sp))
-    atlas = np.zeros((9, th.value, tw.value, 3), dtype=np.uint8)
-    h.rth_model_atlas(handle, atlas.ctypes.data_as(C.c_void_p), C.byref(tw), C.byref(th), C.byref(sp))
-    return Scene(cubes, spheres, mats, lights, cam, amb.value, sky.value, atlas, tw.value, th.value, sp.value, name, handle)
+    nt = C.c_uint32()
+    if h.rth_model_atlas(handle, None, 0, C.byref(nt), C.byref(tw), C.byref(th), C.byref(sp)) != 0:
+        raise RuntimeError("rth_model_atlas: " + h.rth_last_error().decode())
+    atlas = np.zeros((nt.value, th.value, tw.value, 3), dtype=np.uint8)
+    if h.rth_model_atlas(handle, atlas.ctypes.data_as(C.c_void_p), atlas.nbytes, C.byref(nt), C.byref(tw), C.byref(th), C.byref(sp)) != 0:
+        raise RuntimeError("rth_model_atlas: " + h.rth_last_error().decode())
+    sc = Scene(cubes, spheres, mats, lights, cam, amb.value, sky.value, atlas, tw.value, th.value, sp.value, name, handle)
+    sc._owns_model = own
+    return sc
 
 
 def default_scene(material_seed=DEFAULT_MATERIAL_SEED, with_water=False, assets=None):
@@ -98,7 +114,7 @@ def default_scene(material_seed=DEFAULT_MATERIAL_SEED, with_water=False, assets=
     handle = h.rth_model_default(path, material_seed, 1 if with_water else 0)
     if not handle:
         raise RuntimeError("rth_model_default: " + h.rth_last_error().decode())
-    return _scene_from_model(h, handle, "minecraft+water" if with_water else "minecraft")
+    return _scene_from_model(h, handle, "minecraft+water" if with_water else "minecraft", own=True)
 
 
 def synthetic_scene(n_cubes=10000, n_spheres=256, seed=SYNTHETIC_SEED, assets=None):
@@ -108,7 +124,7 @@ def synthetic_scene(n_cubes=10000, n_spheres=256, seed=SYNTHETIC_SEED, assets=No
     handle = h.rth_model_synthetic(path, n_cubes, n_spheres, seed)
     if not handle:
         raise RuntimeError("rth_model_synthetic: " + h.rth_last_error().decode())
-    return _scene_from_model(h, handle, f"synthetic_{n_cubes}c_{n_spheres}s")
+    return _scene_from_model(h, handle, f"synthetic_{n_cubes}c_{n_spheres}s", own=True)
 
 
 def rotate_cam(camera, delta_yaw, delta_pitch):
@@ -169,10 +185,13 @@ class Context:
             scene.atlas.ctypes.data_as(C.c_void_p), scene.atlas.shape[0], scene.tex_w, scene.tex_h, scene.sprite))
         self.scene = scene
 
-    def render(self, frame: Frame, debug=False):
-        """rt_render: returns the band as uint32 [rows, width] (+ dict of debug planes if debug)."""
+    def render(self, frame: Frame, debug=False, out=None):
+        """rt_render: returns the band as uint32 [rows, width] (+ dict of debug planes if debug).
+        `out`: a C-contiguous uint32 [rows, width] array to render into (e.g. PinnedFrame.array)."""
         rows = frame.y1 - frame.y0
-        out = np.empty((rows, frame.width), dtype=np.uint32)
+        if out is None:
+            out = np.empty((rows, frame.width), dtype=np.uint32)
+        assert out.dtype == np.uint32 and out.shape == (rows, frame.width) and out.flags.c_contiguous
         planes = None
         dbg = None
         if debug:
@@ -190,6 +209,10 @@ class Context:
         self._check(self._lib.rt_render_device_part(self._ctx, C.byref(frame), n_parts, part, C.c_void_p(d_out_ptr),
                                                     C.byref(dbg) if dbg is not None else None))
 
+    def render_device_noalloc(self, frame: Frame, d_out_ptr: int):
+        """rt_render_device_noalloc: the allocation-free variant (fixed work buffer per GPU)."""
+        self._check(self._lib.rt_render_device_noalloc(self._ctx, C.byref(frame), C.c_void_p(d_out_ptr)))
+
     def sync(self):
         self._check(self._lib.rt_sync(self._ctx))
 
@@ -197,6 +220,21 @@ class Context:
         c = Counters()
         self._check(self._lib.rt_count_rays_part(self._ctx, C.byref(frame), n_parts, part, C.byref(c)))
         return c
+
+    def count_executed(self, frame: Frame, n_parts=1, part=0):
+        """rt_count_executed: (Counters, ExecCounters) of one counting launch."""
+        c, e = Counters(), ExecCounters()
+        self._check(self._lib.rt_count_executed(self._ctx, C.byref(frame), n_parts, part, C.byref(c), C.byref(e)))
+        return c, e
+
+    def set_tuning(self, key, value):
+        """rt_set_tuning (keys: _ffi.RT_TUNE_*)."""
+        self._check(self._lib.rt_set_tuning(self._ctx, int(key), float(value)))
+
+    def reset_tuning(self):
+        for key, value in ((_ffi.RT_TUNE_COHERENT_SCALE, 1.0), (_ffi.RT_TUNE_SHADOW_LIST, -1), (_ffi.RT_TUNE_DARK_KERNEL, -1),
+                           (_ffi.RT_TUNE_FILL_MEMSET, 0), (_ffi.RT_TUNE_BVH_DEPTH_LIMIT, 28)):
+            self.set_tuning(key, value)
 
     def selftest_division(self, n_cases, seed=1):
         """(mismatches, cases) of the device's shared-reciprocal division against its IEEE division."""
@@ -227,6 +265,40 @@ class Context:
         s = C.c_void_p()
         self._check(self._lib.rt_get_stream(self._ctx, C.byref(s)))
         return s.value or 0
+
+
+def render_multi(ctxs, frame: Frame, d_frame_ptr: int):
+    """rt_render_multi: one frame over several contexts (GPUs), gathered at d_frame_ptr on ctxs[0]'s GPU.
+    Returns the bytes that moved between contexts.  Asynchronous: ctxs[0].sync() waits for the frame."""
+    arr = (C.c_void_p * len(ctxs))(*[c._ctx for c in ctxs])
+    moved = C.c_uint64()
+    rc = _ffi.lib().rt_render_multi(arr, len(ctxs), C.byref(frame), C.c_void_p(d_frame_ptr), C.byref(moved))
+    if rc != RT_OK:
+        raise RtError(rc, _ffi.lib().rt_last_error(ctxs[0]._ctx).decode())
+    return moved.value
+
+
+class PinnedFrame:
+    """A frame in page-locked host memory (rt_host_alloc) as a numpy array: the fast target of rt_render."""
+
+    def __init__(self, rows, width):
+        self._ptr = C.c_void_p()
+        rc = _ffi.lib().rt_host_alloc(rows * width * 4, C.byref(self._ptr))
+        if rc != RT_OK:
+            raise RtError(rc, _ffi.lib().rt_last_error(None).decode())
+        self.array = np.ctypeslib.as_array(C.cast(self._ptr, C.POINTER(C.c_uint32)), shape=(rows, width))
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            _ffi.lib().rt_host_free(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def part_rows(rows, n_parts, part):

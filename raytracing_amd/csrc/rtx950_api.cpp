@@ -5,7 +5,7 @@
 // function of the camera that the reference recomputes per pixel), assemble kernel parameters,
 // launch.  There is no CPU rendering path here: if HIP or the GPU is missing every call fails
 // with RT_ERR_NO_DEVICE / RT_ERR_HIP.
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -23,6 +24,39 @@
 using namespace rtx950;
 
 constexpr uint32_t kDefaultGrid = 32768;  // swept at the end of round 1, one frame at a time: 24576 +2 %, 28672..49152 within 0.5 %, 65536 +1.5 %
+
+// Work buffers of a launch (device memory beyond inputs and outputs): the tile stamps classify_tiles
+// writes, the tile queue build_queue fills, the tile costs render_kernel records.  A context owns a set
+// that grows with the frame size; rt_render_device_noalloc uses the fixed-size set in `scratch` below.
+struct TileScratch {
+    uint32_t* stamps = nullptr;
+    size_t stamps_cap = 0;  // in words
+    uint32_t* queue = nullptr;
+    size_t queue_cap = 0;   // in words
+    uint32_t* cost = nullptr;
+    size_t cost_cap = 0;    // in words
+    uint32_t frame_id = 0;    // stamps equal to the launch's frame id are this launch's (ids only grow)
+    uint32_t launch_seq = 0;  // selects the queue header bank
+    bool growable = true;     // false: fixed capacity, a frame that does not fit is refused (RT_ERR_LIMIT)
+};
+
+// ---- the allocation-free entry point's work buffers (rt_render_device_noalloc) -------------------------
+// One array per GPU, held until the process ends: queue (64 + 9 x tiles words), stamps (64 + tiles + coarse
+// words) and tile costs (tiles + 1 words) for frames of up to RT_NOALLOC_MAX_TILES 8x8 tiles (5.8 MB).
+constexpr size_t kNaTiles = RT_NOALLOC_MAX_TILES;
+constexpr size_t kNaQueueWords = kQueueBase + (kCostClasses + 1) * kNaTiles;
+constexpr size_t kNaStampWords = kStampBase + kNaTiles + kNaTiles / 16 + 64;  // coarse level: <= tiles/64 + (tiles_x + tiles_y)/8 + 1
+constexpr size_t kNaCostWords = kNaTiles + 64;
+constexpr size_t kNaWords = kNaQueueWords + kNaStampWords + kNaCostWords;
+static __device__ __align__(256) uint32_t scratch[kNaWords];
+
+constexpr int kMaxDevices = 64;
+struct DeviceScratch {  // host-side view of one GPU's copy of `scratch`
+    std::mutex mu;
+    bool ready = false;
+    TileScratch ts;
+};
+static DeviceScratch g_dev_scratch[kMaxDevices];
 
 struct rt_ctx {
     int device = 0;
@@ -58,17 +92,16 @@ struct rt_ctx {
     uint32_t* d_dbg[3] = {nullptr, nullptr, nullptr};
     size_t dbg_capacity[3] = {0, 0, 0};
     unsigned long long* d_counters = nullptr;
-    // per-frame tile stamps (classify_tiles)
-    uint32_t* d_stamps = nullptr;
-    size_t stamps_cap = 0;  // in words
-    uint32_t frame_id = 0;
-    // work queue of the render kernel (build_queue)
-    uint32_t* d_queue = nullptr;
-    size_t queue_cap = 0;  // in words
-    // cycles per tile in the previous launch (orders the queue)
-    uint32_t* d_cost = nullptr;
-    size_t cost_cap = 0;
-    uint32_t launch_seq = 0;   // selects the queue header bank
+    TileScratch own;  // tile stamps, work queue, tile costs of this context's launches
+    // rt_render_multi: this context's compact part of the frame, and the event that says it has reached GPU0
+    uint32_t* d_part = nullptr;
+    size_t part_capacity = 0;  // in pixels
+    hipEvent_t part_done = nullptr;
+    // tuning / test knobs (rt_set_tuning); the library reads no environment variables
+    float tune_coherent_scale = 1.0f;
+    int tune_shadow_list = -1, tune_dark_kernel = -1;
+    bool tune_fill_memset = false;
+    uint32_t tune_bvh_depth_limit = kBvhStackMax;
     uint32_t max_workgroups = kDefaultGrid;  // grid of render_kernel: 8x the resident single-wave workgroups of an MI355X
     // timing
     bool timing = false;
@@ -101,6 +134,30 @@ int fail_hip(rt_ctx* ctx, hipError_t e, const char* what)
 {
     return fail(ctx, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
+
+// Makes `device` current for the calling thread and restores the caller's device on scope exit.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != device) {
+            status = hipSetDevice(device);
+            if (status == hipSuccess) prev = cur;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ENTER_DEVICE(ctx)                                                     \
+    DeviceGuard guard__((ctx)->device);                                       \
+    if (guard__.status != hipSuccess) return fail_hip(ctx, guard__.status, "hipSetDevice")
 
 #define HIP_TRY(ctx, expr)                                   \
     do {                                                     \
@@ -263,7 +320,22 @@ bool projection_setup(const Params& p, TileParams& t)
 // Per-launch preparation on the context's stream: the work queue (sized for the launch's tile grid, its
 // header zeroed) and the tile stamps (classify_tiles).  On anything irregular (non-finite camera, skewed
 // basis, non-finite bounds) p.tile_stamps stays null and every tile is traced.
-int prepare(rt_ctx* ctx, Params& p)
+int grow(rt_ctx* ctx, TileScratch& ts, uint32_t** buf, size_t* cap, size_t need, const char* what)
+{
+    if (*cap >= need) return RT_OK;
+    if (!ts.growable)
+        return fail(ctx, RT_ERR_LIMIT, std::string("rt_render_device_noalloc: the frame needs more ") + what +
+                                           " than the fixed work buffer holds (RT_NOALLOC_MAX_TILES 8x8 tiles per frame)");
+    if (*buf) HIP_TRY(ctx, hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)buf, need * sizeof(uint32_t)));
+    *cap = need;
+    HIP_TRY(ctx, hipMemsetAsync(*buf, 0, need * sizeof(uint32_t), ctx->stream));
+    return RT_OK;
+}
+
+int prepare(rt_ctx* ctx, Params& p, TileScratch& ts)
 {
     p.tile_stamps = nullptr;
     p.tiles_x = (p.width + 7u) / 8u;
@@ -277,59 +349,45 @@ int prepare(rt_ctx* ctx, Params& p)
     p.grid_ty = my_blocks * 2u;
     const size_t n_tiles = (size_t)p.grid_tx * p.grid_ty;
     const size_t qwords = kQueueBase + (kCostClasses + 1) * n_tiles;
-    if (ctx->queue_cap < qwords) {
-        if (ctx->d_queue) HIP_TRY(ctx, hipFree(ctx->d_queue));
-        ctx->d_queue = nullptr;
-        ctx->queue_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_queue, qwords * sizeof(uint32_t)));
-        ctx->queue_cap = qwords;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, kQueueBase * sizeof(uint32_t), ctx->stream));  // both header banks
-    }
-    p.queue = ctx->d_queue;
-    // Header banks alternate: this launch counts into bank qsel, which the previous launch (or the memset
-    // above) left zeroed, and zeroes the other one for the next launch.
-    p.qsel = (ctx->launch_seq++) & 1u;
-    if (ctx->cost_cap < n_tiles + 1) {
-        if (ctx->d_cost) HIP_TRY(ctx, hipFree(ctx->d_cost));
-        ctx->d_cost = nullptr;
-        ctx->cost_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cost, (n_tiles + 1) * sizeof(uint32_t)));
-        ctx->cost_cap = n_tiles + 1;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_cost, 0, (n_tiles + 1) * sizeof(uint32_t), ctx->stream));  // 0 = unknown
-    }
-    p.tile_cost = ctx->d_cost;
+    // fine stamps per 8x8 tile of the FRAME, then coarse stamps per block of 8x8 tiles
+    const size_t swords = kStampBase + (size_t)p.tiles_x * p.tiles_y + (size_t)((p.tiles_x + 7u) / 8u) * ((p.tiles_y + 7u) / 8u);
+    int rc;
+    // a fresh buffer is all zero: both queue header banks, "unknown" tile costs, no stamps
+    if ((rc = grow(ctx, ts, &ts.queue, &ts.queue_cap, qwords, "queue entries")) != RT_OK) return rc;
+    if ((rc = grow(ctx, ts, &ts.cost, &ts.cost_cap, n_tiles + 1, "tile cost words")) != RT_OK) return rc;
+    const size_t stamps_before = ts.stamps_cap;
+    if ((rc = grow(ctx, ts, &ts.stamps, &ts.stamps_cap, swords, "tile stamps")) != RT_OK) return rc;
+    if (ts.stamps_cap != stamps_before) ts.frame_id = 0u;
+    p.queue = ts.queue;
+    // Header banks alternate: this launch counts into bank qsel, which the previous launch (or the fresh
+    // buffer) left zeroed, and zeroes the other one for the next launch.
+    p.qsel = (ts.launch_seq++) & 1u;
+    p.tile_cost = ts.cost;
+    // The fixed work buffer is shared by every context of its GPU and keeps the last call's contents: its
+    // header bank is cleared here whatever the last call left (a call that failed between its launches, or
+    // another context's launch that is still in flight: such calls race, see rtx950.h).
+    if (!ts.growable) HIP_TRY(ctx, hipMemsetAsync(ts.queue + p.qsel * 16u, 0, 16 * sizeof(uint32_t), ctx->stream));
 
     TileParams t;
     if (!projection_setup(p, t)) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue + (p.qsel ^ 1u) * 16u, 0, 16 * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ts.queue + (p.qsel ^ 1u) * 16u, 0, 16 * sizeof(uint32_t), ctx->stream));
         return RT_OK;
     }
     t.cube_filt = p.cube_filt;
     t.n_cubes = p.n_cubes;
     t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y;
-    t.queue = ctx->d_queue;
+    t.queue = ts.queue;
     t.qsel = p.qsel;
-    // fine stamps per 8x8 tile, then coarse stamps per block of 8x8 tiles
-    const size_t words = kStampBase + (size_t)p.tiles_x * p.tiles_y + (size_t)((p.tiles_x + 7u) / 8u) * ((p.tiles_y + 7u) / 8u);
-    if (ctx->stamps_cap < words) {
-        if (ctx->d_stamps) HIP_TRY(ctx, hipFree(ctx->d_stamps));
-        ctx->d_stamps = nullptr;
-        ctx->stamps_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_stamps, words * sizeof(uint32_t)));
-        ctx->stamps_cap = words;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_stamps, 0, words * sizeof(uint32_t), ctx->stream));
-        ctx->frame_id = 0u;
+    if (++ts.frame_id == 0u) {  // wrapped: stale stamps could alias, start over
+        HIP_TRY(ctx, hipMemsetAsync(ts.stamps, 0, ts.stamps_cap * sizeof(uint32_t), ctx->stream));
+        ts.frame_id = 1u;
     }
-    if (++ctx->frame_id == 0u) {  // wrapped: stale stamps could alias, start over
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_stamps, 0, ctx->stamps_cap * sizeof(uint32_t), ctx->stream));
-        ctx->frame_id = 1u;
-    }
-    t.stamps = ctx->d_stamps;
-    t.frame_id = ctx->frame_id;
+    t.stamps = ts.stamps;
+    t.frame_id = ts.frame_id;
     hipError_t e = (hipError_t)launch_classify(t, (void*)ctx->stream);  // also zeroes the next header bank
     if (e != hipSuccess) return fail_hip(ctx, e, "classify kernel launch");
-    p.tile_stamps = ctx->d_stamps;
-    p.frame_id = ctx->frame_id;
+    p.tile_stamps = ts.stamps;
+    p.frame_id = ts.frame_id;
     return RT_OK;
 }
 
@@ -383,7 +441,8 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= n) return fail(nullptr, RT_ERR_NO_DEVICE, "device ordinal out of range");
-    HIP_TRY(nullptr, hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail_hip(nullptr, guard.status, "hipSetDevice");
     rt_ctx* c = new rt_ctx();
     c->device = device;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -397,7 +456,30 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
         delete c;
         return fail_hip(nullptr, e, "hipMalloc(counters)");
     }
-    if (const char* g = getenv("RTX950_GRID")) { long v = atol(g); if (v > 0 && v < (1l << 30)) c->max_workgroups = (uint32_t)v; }  // tuning experiments
+    // The fixed work buffer of rt_render_device_noalloc: this device's copy of `scratch`, looked up once per
+    // device with the device current (in host code the array's name is not a device address).
+    if (device < kMaxDevices) {
+        DeviceScratch& ds = g_dev_scratch[device];
+        std::lock_guard<std::mutex> lock(ds.mu);
+        if (!ds.ready) {
+            uint32_t* base = nullptr;
+            e = hipGetSymbolAddress((void**)&base, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !base) {
+                (void)hipFree(c->d_counters);
+                (void)hipStreamDestroy(c->stream);
+                delete c;
+                return fail_hip(nullptr, e, "hipGetSymbolAddress(scratch)");
+            }
+            ds.ts.queue = base;
+            ds.ts.queue_cap = kNaQueueWords;
+            ds.ts.stamps = base + kNaQueueWords;
+            ds.ts.stamps_cap = kNaStampWords;
+            ds.ts.cost = base + kNaQueueWords + kNaStampWords;
+            ds.ts.cost_cap = kNaCostWords;
+            ds.ts.growable = false;
+            ds.ready = true;
+        }
+    }
     *out_ctx = c;
     return RT_OK;
 }
@@ -405,15 +487,17 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
 int rt_ctx_destroy(rt_ctx* ctx)
 {
     if (!ctx) return RT_OK;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     (void)hipFree(ctx->d_fb);
     for (auto& b : ctx->d_dbg) (void)hipFree(b);
     (void)hipFree(ctx->d_counters);
-    (void)hipFree(ctx->d_stamps);
-    (void)hipFree(ctx->d_queue);
-    (void)hipFree(ctx->d_cost);
+    (void)hipFree(ctx->own.stamps);
+    (void)hipFree(ctx->own.queue);
+    (void)hipFree(ctx->own.cost);
+    (void)hipFree(ctx->d_part);
+    if (ctx->part_done) (void)hipEventDestroy(ctx->part_done);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(ctx->stream);
@@ -442,7 +526,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     for (size_t i = 0; i < n_spheres; ++i)
         if (spheres[i].material >= n_materials) return fail(ctx, RT_ERR_INVALID_ARG, "sphere references a material outside the table");
 
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
 
@@ -568,7 +652,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
         for (size_t i = 0; i < n_cubes; ++i) ident[i] = (uint32_t)i;
         const double list_extent = chunk_boxes(ident.data(), hbox_list);
         shadow_list = std::isfinite(list_extent) && std::isfinite(morton_extent) && list_extent <= 3.0 * morton_extent;
-        if (const char* e = getenv("RTX950_SHADOW_LIST")) shadow_list = atoi(e) != 0;  // tuning experiments / tests
+        if (ctx->tune_shadow_list >= 0) shadow_list = ctx->tune_shadow_list != 0;  // rt_set_tuning: tests force either stream
         if (shadow_list) {
             hf_list.resize(n_filt * 4);
             hid_list.assign(n_filt, 0u);
@@ -707,8 +791,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.bvh = ctx->d_bvh;
     b.n_bvh_nodes = (uint32_t)nodes.size();
     b.coherent_thr = half_n ? (float)(8.0 * half_sum / (double)half_n) : 0.0f;  // 8 average half sizes (swept with the ordered walk: 4..16 within 10 %)
-    if (bvh_depth > kBvhStackMax) b.coherent_thr = INFINITY;  // a list too long for the walk's per-lane stack: every wave takes the chunk traversal
-    if (const char* e = getenv("RTX950_COHERENT_SCALE")) b.coherent_thr *= (float)atof(e);  // tuning experiments
+    if (bvh_depth > ctx->tune_bvh_depth_limit) b.coherent_thr = INFINITY;  // a list too long for the walk's per-lane stack: every wave takes the chunk traversal
+    if (std::isfinite(b.coherent_thr)) b.coherent_thr *= ctx->tune_coherent_scale;  // rt_set_tuning: 1 unless a test forces one traversal
     b.spheres = ctx->d_spheres;
     b.sphere_meta = ctx->d_sphere_meta;
     b.sphere_filt = ctx->d_sphere_filt;
@@ -720,7 +804,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.dark_materials = 0u;
     for (size_t i = 0; i < n_materials; ++i)
         if (!(1.0f - materials[i].reflectivity - materials[i].transparency >= 0.01f)) b.dark_materials = 1u;
-    if (getenv("RTX950_DARK_KERNEL")) b.dark_materials = atoi(getenv("RTX950_DARK_KERNEL")) ? 1u : 0u;  // parity tests: either kernel for any scene
+    if (ctx->tune_dark_kernel >= 0) b.dark_materials = ctx->tune_dark_kernel ? 1u : 0u;  // rt_set_tuning: either kernel for any scene
     b.atlas = ctx->d_atlas;
     b.n_cubes = (uint32_t)n_cubes;
     b.n_spheres = (uint32_t)n_spheres;
@@ -757,7 +841,7 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
     if (rc != RT_OK) return rc;
     if (!d_out_0rgb) return fail(ctx, RT_ERR_INVALID_ARG, "output pointer is null");
     if (n_parts == 0u || part >= n_parts) return fail(ctx, RT_ERR_INVALID_ARG, "need 0 <= part < n_parts");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     Params p;
     fill_frame(ctx, frame, p);
     p.n_parts = n_parts;
@@ -766,7 +850,7 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
 #ifdef RTX_PROFILE
     p.counters = ctx->d_counters;
 #endif
-    if ((rc = prepare(ctx, p)) != RT_OK) return rc;
+    if ((rc = prepare(ctx, p, ctx->own)) != RT_OK) return rc;
     int variant = kVariantRender;
     if (dbg_device && (dbg_device->hit_cube || dbg_device->hit_sphere || dbg_device->tree_hash)) {
         p.hit_cube = dbg_device->hit_cube;
@@ -781,7 +865,7 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
         // with debug planes or counters still paint and count).  A buffer or width that 16-byte stores do not
         // fit is filled by the runtime ahead of the launches instead (33 MB at 4K in 20 us).
         const size_t npx = (size_t)rt_part_rows(frame->y1 - frame->y0, n_parts, part) * frame->width;
-        if (((uintptr_t)d_out_0rgb & 15u) == 0u && (frame->width & 3u) == 0u && getenv("RTX950_FILL_MEMSET") == nullptr) {
+        if (((uintptr_t)d_out_0rgb & 15u) == 0u && (frame->width & 3u) == 0u && !ctx->tune_fill_memset) {
             p.prefilled = 2u;  // build_queue paints the tiles it does not list (16-byte stores)
         } else {
             if (npx) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_out_0rgb, (int)p.sky, npx, ctx->stream));
@@ -796,7 +880,7 @@ int rt_render(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_0rgb, const rt_d
     int rc = check_frame(ctx, frame);
     if (rc != RT_OK) return rc;
     if (!out_0rgb) return fail(ctx, RT_ERR_INVALID_ARG, "output pointer is null");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const size_t npx = (size_t)(frame->y1 - frame->y0) * frame->width;
     if ((rc = ensure(ctx, &ctx->d_fb, &ctx->fb_capacity, npx)) != RT_OK) return rc;
     rt_debug_planes dev{nullptr, nullptr, nullptr};
@@ -826,7 +910,7 @@ int rt_render(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_0rgb, const rt_d
 int rt_sync(rt_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -835,41 +919,64 @@ int rt_count_rays(rt_ctx* ctx, const rt_frame* frame, rt_counters* out) { return
 
 int rt_count_rays_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, rt_counters* out)
 {
+    return rt_count_executed(ctx, frame, n_parts, part, out, nullptr);
+}
+
+int rt_count_executed(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, rt_counters* out, rt_exec_counters* exec)
+{
     int rc = check_frame(ctx, frame);
     if (rc != RT_OK) return rc;
-    if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "out is null");
+    if (!out && !exec) return fail(ctx, RT_ERR_INVALID_ARG, "out is null");
     if (n_parts == 0u || part >= n_parts) return fail(ctx, RT_ERR_INVALID_ARG, "need 0 <= part < n_parts");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     Params p;
     fill_frame(ctx, frame, p);
     p.n_parts = n_parts;
     p.part = part;
     p.counters = ctx->d_counters;
-    if ((rc = prepare(ctx, p)) != RT_OK) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    if ((rc = prepare(ctx, p, ctx->own)) != RT_OK) return rc;
+    constexpr size_t kWords = 10 + RT_EXEC_EVENTS;
+    static_assert(kWords * sizeof(unsigned long long) <= kCounterBytes, "counter buffer too small");
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, kWords * sizeof(unsigned long long), ctx->stream));
     if ((rc = listing(ctx, p, kVariantCount)) != RT_OK) return rc;
     hipError_t e = (hipError_t)launch_render(p, kVariantCount, (void*)ctx->stream, ctx->max_workgroups);
     if (e != hipSuccess) return fail_hip(ctx, e, "count kernel launch");
-    unsigned long long h[10];
+    unsigned long long h[kWords];
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    out->nearest_rays = h[0];
-    out->shadow_rays = h[1];
-    out->cube_tests = h[2];
-    out->sphere_tests = h[3];
-    out->shaded_hits = h[4];
-    out->ref_nearest_rays = h[5];
-    out->ref_shadow_rays = h[6];
-    out->ref_cube_tests = h[7];
-    out->ref_sphere_tests = h[8];
-    out->ref_shaded_hits = h[9];
+    if (out) {
+        out->nearest_rays = h[0];
+        out->shadow_rays = h[1];
+        out->cube_tests = h[2];
+        out->sphere_tests = h[3];
+        out->shaded_hits = h[4];
+        out->ref_nearest_rays = h[5];
+        out->ref_shadow_rays = h[6];
+        out->ref_cube_tests = h[7];
+        out->ref_sphere_tests = h[8];
+        out->ref_shaded_hits = h[9];
+    }
+    if (exec) {
+        exec->cull_tests = h[10];
+        exec->chunk_tests = h[11];
+        exec->candidate_evals = h[12];
+        exec->exact_evals = h[13];
+        exec->bvh_steps = h[14];
+        exec->sphere_evals = h[15];
+        exec->queries = h[16];
+        exec->light_iterations = h[17];
+        exec->resolved_hits = h[18];
+        exec->blockers = h[19];
+        exec->child_setups = h[20];
+        exec->primary_rays = h[21];
+    }
     return RT_OK;
 }
 
 int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t* out_mismatches, uint64_t* out_cases)
 {
     if (!ctx || !out_mismatches || !out_cases) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const uint32_t iters = 4096u;
     uint64_t blocks64 = (n_cases + 256ull * iters - 1ull) / (256ull * iters);
     if (blocks64 == 0) blocks64 = 1;
@@ -906,7 +1013,7 @@ int rt_set_grid_limit(rt_ctx* ctx, uint32_t max_workgroups)
 int rt_kernel_time_ms(rt_ctx* ctx, double* out_avg_ms, uint32_t* out_launches)
 {
     if (!ctx || !out_avg_ms || !out_launches) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     double total = 0.0;
     for (auto& ev : ctx->events) {
@@ -1012,6 +1119,191 @@ int rt_frame_row_extent(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_y_firs
     *out_y_end = y_end;
     remember();
     return RT_OK;
+}
+
+int rt_set_tuning(rt_ctx* ctx, int key, double value)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
+    const bool tri = (value == -1.0 || value == 0.0 || value == 1.0);
+    switch (key) {
+    case RT_TUNE_COHERENT_SCALE:
+        if (!(value >= 0.0)) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_COHERENT_SCALE must be >= 0");
+        ctx->tune_coherent_scale = (float)value;
+        return RT_OK;
+    case RT_TUNE_SHADOW_LIST:
+        if (!tri) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_SHADOW_LIST must be -1 (automatic), 0 or 1");
+        ctx->tune_shadow_list = (int)value;
+        return RT_OK;
+    case RT_TUNE_DARK_KERNEL:
+        if (!tri) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_DARK_KERNEL must be -1 (automatic), 0 or 1");
+        ctx->tune_dark_kernel = (int)value;
+        return RT_OK;
+    case RT_TUNE_FILL_MEMSET:
+        if (!(value == 0.0 || value == 1.0)) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_FILL_MEMSET must be 0 or 1");
+        ctx->tune_fill_memset = value != 0.0;
+        return RT_OK;
+    case RT_TUNE_BVH_DEPTH_LIMIT:
+        if (!(value >= 1.0 && value <= (double)kBvhStackMax && value == (double)(uint32_t)value))
+            return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_BVH_DEPTH_LIMIT must be an integer in 1..28");
+        ctx->tune_bvh_depth_limit = (uint32_t)value;
+        return RT_OK;
+    default:
+        return fail(ctx, RT_ERR_INVALID_ARG, "unknown tuning key");
+    }
+}
+
+int rt_host_alloc(size_t bytes, void** out_ptr)
+{
+    if (!out_ptr) return fail(nullptr, RT_ERR_INVALID_ARG, "out_ptr is null");
+    *out_ptr = nullptr;
+    if (bytes == 0) return fail(nullptr, RT_ERR_INVALID_ARG, "zero bytes");
+    HIP_TRY(nullptr, hipHostMalloc(out_ptr, bytes, hipHostMallocPortable));
+    return RT_OK;
+}
+
+int rt_host_free(void* ptr)
+{
+    if (!ptr) return RT_OK;
+    HIP_TRY(nullptr, hipHostFree(ptr));
+    return RT_OK;
+}
+
+// The allocation-free variant of rt_render_device: the same kernels, with the tile stamps, the tile queue
+// and the tile costs in this GPU's copy of the file-scope array `scratch` instead of buffers the context
+// allocates and grows.  Calls no hipMalloc/hipFree, creates no events.
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out_0rgb)
+{
+    int rc = check_frame(ctx, frame);
+    if (rc != RT_OK) return rc;
+    if (!d_out_0rgb) return fail(ctx, RT_ERR_INVALID_ARG, "output pointer is null");
+    if (ctx->device >= kMaxDevices || !g_dev_scratch[ctx->device].ready)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "no fixed work buffer for this device");
+    const uint64_t frame_tiles = (uint64_t)((frame->width + 7u) / 8u) * ((frame->height + 7u) / 8u);
+    if (frame_tiles > RT_NOALLOC_MAX_TILES)
+        return fail(ctx, RT_ERR_LIMIT, "rt_render_device_noalloc: frame has " + std::to_string(frame_tiles) +
+                                           " 8x8 tiles, the fixed work buffer holds RT_NOALLOC_MAX_TILES = " + std::to_string(RT_NOALLOC_MAX_TILES));
+    ENTER_DEVICE(ctx);
+    DeviceScratch& ds = g_dev_scratch[ctx->device];
+    std::lock_guard<std::mutex> lock(ds.mu);  // host-side bookkeeping only: launches of overlapping calls still race on the device
+    Params p;
+    fill_frame(ctx, frame, p);
+    p.out = d_out_0rgb;
+    if ((rc = prepare(ctx, p, ds.ts)) != RT_OK) return rc;
+    if (((uintptr_t)d_out_0rgb & 15u) == 0u && (frame->width & 3u) == 0u && !ctx->tune_fill_memset) {
+        p.prefilled = 2u;
+    } else {
+        const size_t npx = (size_t)(frame->y1 - frame->y0) * frame->width;
+        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_out_0rgb, (int)p.sky, npx, ctx->stream));
+        p.prefilled = 1u;
+    }
+    if ((rc = listing(ctx, p, kVariantRender)) != RT_OK) return rc;
+    hipError_t e = (hipError_t)launch_render(p, kVariantRender, (void*)ctx->stream, ctx->max_workgroups);
+    if (e != hipSuccess) return fail_hip(ctx, e, "render kernel launch");
+    return RT_OK;
+}
+
+// Scatter of the compact parts into frame order on ctxs[0]'s GPU: part g's k-th 16-row block is block
+// k * n + g of the band, so a part is one strided 2-D copy (rows of 16 * width pixels, destination pitch
+// n such rows) plus, for the part that owns the band's ragged last block, one short copy.  Each copy runs
+// on the stream of the context that rendered the part, i.e. behind its render with no host wait; GPU0's
+// stream then waits for every part's event.
+int rt_gather_bands(rt_ctx* const* ctxs, uint32_t n_ctx, const uint32_t* const* d_parts, uint32_t width, uint32_t rows,
+                    uint32_t* d_band_on_ctx0, uint64_t* out_bytes_moved)
+{
+    if (!ctxs || n_ctx == 0u || !ctxs[0]) return fail(nullptr, RT_ERR_INVALID_ARG, "ctxs is null or empty");
+    rt_ctx* c0 = ctxs[0];
+    if (!d_parts || !d_band_on_ctx0 || width == 0u) return fail(c0, RT_ERR_INVALID_ARG, "null argument");
+    for (uint32_t g = 0; g < n_ctx; ++g)
+        if (!ctxs[g] || !d_parts[g]) return fail(c0, RT_ERR_INVALID_ARG, "a context or part buffer is null");
+    const uint32_t blocks = (rows + kRowBlock - 1u) / kRowBlock;
+    const size_t block_bytes = (size_t)kRowBlock * width * sizeof(uint32_t);
+    uint64_t moved = 0;
+    for (uint32_t g = 0; g < n_ctx; ++g) {
+        rt_ctx* c = ctxs[g];
+        ENTER_DEVICE(c);
+        if (c->device != c0->device) {
+            hipError_t pe = hipDeviceEnablePeerAccess(c0->device, 0);
+            if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // sticky-free status: already on
+            else if (pe != hipSuccess) return fail_hip(c0, pe, "hipDeviceEnablePeerAccess");
+        }
+        const uint32_t my_blocks = (g < blocks) ? (blocks - g + n_ctx - 1u) / n_ctx : 0u;
+        if (my_blocks == 0u) continue;
+        // the band's last block may be ragged; it belongs to part (blocks - 1) % n_ctx and is that part's last
+        const bool ragged = (rows % kRowBlock != 0u) && ((blocks - 1u) % n_ctx == g);
+        const uint32_t full = ragged ? my_blocks - 1u : my_blocks;
+        uint32_t* dst = d_band_on_ctx0 + (size_t)g * kRowBlock * width;
+        if (full)
+            HIP_TRY(c0, hipMemcpy2DAsync(dst, block_bytes * n_ctx, d_parts[g], block_bytes, block_bytes, full, hipMemcpyDeviceToDevice, c->stream));
+        if (ragged) {
+            const size_t tail_bytes = (size_t)(rows % kRowBlock) * width * sizeof(uint32_t);
+            HIP_TRY(c0, hipMemcpyAsync(dst + (size_t)full * n_ctx * kRowBlock * width, d_parts[g] + (size_t)full * kRowBlock * width, tail_bytes,
+                                       hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (c != c0) moved += (uint64_t)rt_part_rows(rows, n_ctx, g) * width * sizeof(uint32_t);
+        if (c->stream != c0->stream) {
+            if (!c->part_done) HIP_TRY(c0, hipEventCreateWithFlags(&c->part_done, hipEventDisableTiming));
+            HIP_TRY(c0, hipEventRecord(c->part_done, c->stream));
+        }
+    }
+    {
+        ENTER_DEVICE(c0);
+        for (uint32_t g = 1; g < n_ctx; ++g)
+            if (ctxs[g]->stream != c0->stream && ctxs[g]->part_done) HIP_TRY(c0, hipStreamWaitEvent(c0->stream, ctxs[g]->part_done, 0));
+    }
+    if (out_bytes_moved) *out_bytes_moved = moved;
+    return RT_OK;
+}
+
+// One frame on n GPUs from one host thread: the rows that can hold geometry (rt_frame_row_extent) are cut
+// into 16-row blocks dealt round-robin to the contexts, each renders its blocks into a buffer of its own
+// and rt_gather_bands moves them into the frame on ctxs[0]'s GPU; that GPU fills the sky rows itself.
+int rt_render_multi(rt_ctx* const* ctxs, uint32_t n_ctx, const rt_frame* frame, uint32_t* d_frame_on_ctx0, uint64_t* out_bytes_moved)
+{
+    if (!ctxs || n_ctx == 0u || !ctxs[0]) return fail(nullptr, RT_ERR_INVALID_ARG, "ctxs is null or empty");
+    rt_ctx* c0 = ctxs[0];
+    int rc = check_frame(c0, frame);
+    if (rc != RT_OK) return rc;
+    if (!d_frame_on_ctx0) return fail(c0, RT_ERR_INVALID_ARG, "output pointer is null");
+    for (uint32_t g = 1; g < n_ctx; ++g) {
+        if (!ctxs[g]) return fail(c0, RT_ERR_INVALID_ARG, "a context is null");
+        if ((rc = check_frame(ctxs[g], frame)) != RT_OK) return fail(c0, rc, std::string("context ") + std::to_string(g) + ": " + ctxs[g]->err);
+        for (uint32_t k = 0; k < g; ++k)
+            if (ctxs[k] == ctxs[g]) return fail(c0, RT_ERR_INVALID_ARG, "the same context is listed twice (one context per part)");
+    }
+    uint32_t ya = frame->y0, yb = frame->y1;
+    if ((rc = rt_frame_row_extent(c0, frame, &ya, &yb)) != RT_OK) return rc;
+    // the sub-band that is rendered: from the 16-row block of the band that holds ya to yb
+    const uint32_t w = frame->width;
+    const uint32_t s0 = frame->y0 + ((ya - frame->y0) / kRowBlock) * kRowBlock, s1 = yb;
+    {
+        ENTER_DEVICE(c0);
+        const uint32_t sky = frame->sky_0rgb & 0x00FFFFFFu;
+        const size_t head = (size_t)((s1 > s0 ? s0 : frame->y1) - frame->y0) * w;  // nothing to render: the whole band is sky
+        if (head) HIP_TRY(c0, hipMemsetD32Async((hipDeviceptr_t)d_frame_on_ctx0, (int)sky, head, c0->stream));
+        if (s1 > s0 && s1 < frame->y1)
+            HIP_TRY(c0, hipMemsetD32Async((hipDeviceptr_t)(d_frame_on_ctx0 + (size_t)(s1 - frame->y0) * w), (int)sky, (size_t)(frame->y1 - s1) * w, c0->stream));
+        // the reference's never-painted pixel i == width (render.rs:316-322) when its row is one of the filled ones
+        if (frame->y0 <= 1u && 1u < frame->y1 && !(s1 > s0 && s0 <= 1u && 1u < s1))
+            HIP_TRY(c0, hipMemsetD32Async((hipDeviceptr_t)(d_frame_on_ctx0 + (size_t)(1u - frame->y0) * w), 0, 1, c0->stream));
+    }
+    if (!(s1 > s0)) {
+        if (out_bytes_moved) *out_bytes_moved = 0;
+        return RT_OK;
+    }
+    rt_frame sub = *frame;
+    sub.y0 = s0;
+    sub.y1 = s1;
+    std::vector<const uint32_t*> parts(n_ctx, nullptr);
+    for (uint32_t g = 0; g < n_ctx; ++g) {
+        rt_ctx* c = ctxs[g];
+        ENTER_DEVICE(c);
+        const size_t need = (size_t)rt_part_rows(s1 - s0, n_ctx, g) * w;
+        if ((rc = ensure(c, &c->d_part, &c->part_capacity, need ? need : 1)) != RT_OK) return fail(c0, rc, c->err);
+        parts[g] = c->d_part;
+        if (need && (rc = rt_render_device_part(c, &sub, n_ctx, g, c->d_part, nullptr)) != RT_OK) return fail(c0, rc, c->err);
+    }
+    // GPU0's fills above run on its stream; the parts' copies run on theirs and touch other rows
+    return rt_gather_bands(ctxs, n_ctx, parts.data(), w, s1 - s0, d_frame_on_ctx0 + (size_t)(s0 - frame->y0) * w, out_bytes_moved);
 }
 
 int rt_get_stream(rt_ctx* ctx, void** out_hip_stream)

@@ -156,11 +156,16 @@ DEV Col col_add(Col a, Col b)
 }
 
 // ---------------------------------------------------------------- counters (count variant only)
+// Executed-work events (count variant only): what the kernel actually evaluates, per lane, as opposed to
+// the reference's brute-force tests above.  bench.py turns them into executed FP32 operations with the
+// per-event costs listed in DESIGN.md ("Roofline").
+enum { EV_CULL = 0, EV_CHUNK, EV_CAND, EV_EXACT, EV_BVH, EV_SPHERE, EV_QUERY, EV_LIGHT, EV_RESOLVE, EV_BLOCKER, EV_CHILD, EV_PRIMARY, EV_COUNT };
 struct Counters {  // per ray-tree node
     uint32_t nearest_rays, shadow_rays, cube_tests, sphere_tests, shaded_hits;
+    uint32_t ev[EV_COUNT];
 };
-struct Totals {  // per lane: [0..4] unique work, [5..9] the reference's n_lights^depth-weighted work
-    unsigned long long v[10];
+struct Totals {  // per lane: [0..4] unique work, [5..9] the reference's n_lights^depth-weighted work, [10..] executed events
+    unsigned long long v[10 + EV_COUNT];
 };
 DEV void totals_add(Totals& t, const Counters& c, unsigned long long w)
 {
@@ -170,6 +175,8 @@ DEV void totals_add(Totals& t, const Counters& c, unsigned long long w)
         t.v[k] += a[k];
         t.v[5 + k] += (unsigned long long)a[k] * w;
     }
+#pragma unroll
+    for (int k = 0; k < EV_COUNT; ++k) t.v[10 + k] += c.ev[k];
 }
 
 // ---------------------------------------------------------------- conservative cube filter
@@ -698,6 +705,8 @@ struct QState {
     uint32_t blocker;   //           ... lowest list index so far (kNoHit: none)
     float tol;          // the ray's 2E (out)
     bool div_ok;        // the ray's RayPre::div_ok (out)
+    // executed-work events of this query, per lane (read by the count variant only; dead code elsewhere)
+    uint32_t ev_cull, ev_chunk, ev_cand, ev_exact, ev_bvh;
 };
 
 // One candidate cube (list index i, id cid, centre k, half size kh) against the wave's rays.  UNIFORM:
@@ -731,6 +740,8 @@ DEV void cube_candidate(const Params& P, const RayPre& q, bool active, bool any_
     }
     const bool amb = live && !sure;
     float dist = (lo < 0.0f) ? hi : lo;  // cube.rs:145 on the approximate interval
+    st.ev_cand += active ? 1u : 0u;
+    st.ev_exact += amb ? 1u : 0u;
     PROF_COUNT(0, 1);
     PROF_KCOUNT(ck, 1);
     PROF_COUNT(1, wave_any(amb) ? 1 : 0);
@@ -786,6 +797,7 @@ DEV void cube_query_small(const Params& P, const RayPre& q, const CullPre& cp, b
         uint32_t ids = 0u;
         if constexpr (MODE == Q_SHADOW) ids = P.cube_id[base + lane];
         unsigned long long M = wave_ballot(cull_test(rec, cp) && (base + lane < n));
+        st.ev_cull += (base + lane < n) ? 1u : 0u;
         PROF_MARK(PH_CULL);
         while (M != 0ull) {
             const uint32_t b = (uint32_t)__builtin_ctzll(M);
@@ -848,6 +860,7 @@ DEV void cube_query_large(const Params& P, const RayPre& q, const CullPre& cp, b
     for (uint32_t cg = 0; cg < n_chunks; cg += 64u) {
         const f32x4 bk = boxes[(size_t)(cg + lane) * 2u], bh = boxes[(size_t)(cg + lane) * 2u + 1u];  // padded to a multiple of 64 chunks
         unsigned long long CM = wave_ballot(chunk_test(bk, bh, cp) && (cg + lane < n_chunks));
+        st.ev_chunk += (cg + lane < n_chunks) ? 1u : 0u;
         const float bk3 = bk[3];  // scalar copy first: see the note at u2f
         const uint32_t chunk_first = __builtin_bit_cast(uint32_t, bk3);  // lowest list index in lane's chunk
         bool refresh = true;  // Q_SHADOW: some lane's blocker may have changed since the chunks were last screened
@@ -884,6 +897,7 @@ DEV void cube_query_large(const Params& P, const RayPre& q, const CullPre& cp, b
             uint32_t ids = 0u;
             if constexpr (MODE == Q_SHADOW) ids = id_stream[base + lane];
             unsigned long long M = wave_ballot(cull_test(rec, cp) && (base + lane < n));
+            st.ev_cull += (base + lane < n) ? 1u : 0u;
             PROF_MARK(PH_CULL);
             while (M != 0ull) {
                 const uint32_t b = (uint32_t)__builtin_ctzll(M);
@@ -965,6 +979,7 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
     while (wave_any(pair != kNone)) {
         PROF_COUNT(MODE == Q_SHADOW ? 4 : 3, 1);  // profile builds: walk steps (drown the few amb counts of these slots)
         const bool on = pair != kNone;
+        st.ev_bvh += on ? 1u : 0u;
         const size_t pi = on ? (size_t)pair * 4u : 0u;
         const f32x4 ac = nodes[pi], ah = nodes[pi + 1u], bc = nodes[pi + 2u], bh = nodes[pi + 3u];
         const float ac3 = ac[3], ah3 = ah[3], bc3 = bc[3], bh3 = bh[3];  // scalar copies first: see the note at u2f
@@ -1053,7 +1068,7 @@ DEV bool ray_wild(const Params& P, V3 o, V3 d)
 // NEAREST: render.rs:87-101 over the sphere list (strict <, list order).  SHADOW: render.rs:44-70, the
 // first sphere in list order whose id differs from the impact object's and that is hit.
 template <bool SHADOW>
-DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, uint32_t& best_idx, float& best_dist)
+DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, uint32_t& best_idx, float& best_dist, uint32_t& ev_cull, uint32_t& ev_sphere)
 {
     const uint32_t n = P.n_spheres;
     if (n == 0u) return;
@@ -1066,6 +1081,7 @@ DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_
         f32x4 rec = filt[base + lane];  // (centre, |radius|), padded to a multiple of 64
         rec[3] = __builtin_fmaf(grow, __builtin_amdgcn_rcpf(rec[3]), rec[3]);
         unsigned long long M = wave_ballot(cull_test(rec, cp) && (base + lane < n));
+        ev_cull += (base + lane < n) ? 1u : 0u;
         while (M != 0ull) {
             const uint32_t b = (uint32_t)__builtin_ctzll(M);
             M &= M - 1ull;
@@ -1073,6 +1089,7 @@ DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_
             const SphereRec s = load_sphere_uniform(P.spheres, i);
             float dist = 0.0f;
             const bool hit = sphere_exact(s, o, d, dist);
+            ev_sphere += active ? 1u : 0u;
             if constexpr (SHADOW) {
                 const bool pass = hit && active && !done && (load_sphere_meta_uniform(P.sphere_meta, i).id != impact_id);
                 best_idx = pass ? i : best_idx;
@@ -1099,6 +1116,7 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
         QState st;
         st.b1 = __builtin_inff(); st.b2 = __builtin_inff(); st.i1 = kNoHit;
         st.best = __builtin_inff(); st.best_i = kNoHit; st.done = false; st.blocker = kNoHit; st.tol = 0.0f; st.div_ok = false;
+        st.ev_cull = 0u; st.ev_chunk = 0u; st.ev_cand = 0u; st.ev_exact = 0u; st.ev_bvh = 0u;
         cube_query<Q_NEAREST, LARGE>(P, active, o, d, 0u, st PROF_PASS);
         best_idx = active ? st.i1 : kNoHit;
         div_ok = st.div_ok;
@@ -1108,14 +1126,26 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
             cube_query<Q_NEAREST_EXACT, LARGE>(P, contested, o, d, 0u, st PROF_PASS);
             PROF_MARK(PH_CONTESTED);
             best_idx = contested ? st.best_i : best_idx;
+            if constexpr (COUNT) cnt.ev[EV_QUERY] += contested ? 1u : 0u;
         }
-        if constexpr (COUNT) cnt.cube_tests += active ? P.n_cubes : 0u;
+        if constexpr (COUNT) {
+            cnt.cube_tests += active ? P.n_cubes : 0u;
+            cnt.ev[EV_CULL] += st.ev_cull; cnt.ev[EV_CHUNK] += st.ev_chunk; cnt.ev[EV_CAND] += st.ev_cand;
+            cnt.ev[EV_EXACT] += st.ev_exact; cnt.ev[EV_BVH] += st.ev_bvh;
+        }
     } else {
         float best_dist = __builtin_inff();
-        sphere_query<false>(P, active, o, d, 0u, best_idx, best_dist);
-        if constexpr (COUNT) cnt.sphere_tests += active ? P.n_spheres : 0u;
+        uint32_t ev_cull = 0u, ev_sphere = 0u;
+        sphere_query<false>(P, active, o, d, 0u, best_idx, best_dist, ev_cull, ev_sphere);
+        if constexpr (COUNT) {
+            cnt.sphere_tests += active ? P.n_spheres : 0u;
+            cnt.ev[EV_CULL] += ev_cull; cnt.ev[EV_SPHERE] += ev_sphere;
+        }
     }
-    if constexpr (COUNT) cnt.nearest_rays += active ? 1u : 0u;
+    if constexpr (COUNT) {
+        cnt.nearest_rays += active ? 1u : 0u;
+        cnt.ev[EV_QUERY] += active ? 1u : 0u;
+    }
     return best_idx;
 }
 
@@ -1128,13 +1158,22 @@ DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V
     // dir = normalize(light_pos - origin) (render.rs:46), the caller's light_dir: the same expression
     blocker = kNoHit;
     float sdist = 0.0f;
-    if constexpr (COUNT) cnt.shadow_rays += active ? 1u : 0u;
+    if constexpr (COUNT) {
+        cnt.shadow_rays += active ? 1u : 0u;
+        cnt.ev[EV_QUERY] += active ? 1u : 0u;
+    }
     if (pass == PASS_CUBES) {
         QState st;
         st.b1 = 0.0f; st.b2 = 0.0f; st.i1 = kNoHit; st.best = 0.0f; st.best_i = kNoHit;
         st.done = false; st.blocker = kNoHit; st.tol = 0.0f; st.div_ok = false;
+        st.ev_cull = 0u; st.ev_chunk = 0u; st.ev_cand = 0u; st.ev_exact = 0u; st.ev_bvh = 0u;
         cube_query<Q_SHADOW, LARGE>(P, active, origin, dir, impact_id, st PROF_PASS);
         blocker = (active && st.done) ? st.blocker : kNoHit;
+        if constexpr (COUNT) {
+            cnt.ev[EV_CULL] += st.ev_cull; cnt.ev[EV_CHUNK] += st.ev_chunk; cnt.ev[EV_CAND] += st.ev_cand;
+            cnt.ev[EV_EXACT] += st.ev_exact; cnt.ev[EV_BVH] += st.ev_bvh;
+            cnt.ev[EV_BLOCKER] += (blocker != kNoHit) ? 1u : 0u;
+        }
         if (wave_any(blocker != kNoHit)) {
             // the blocker's exact distance (per-lane gather; the loop only proved that it passes)
             const CubeRec c = P.cubes[blocker != kNoHit ? blocker : 0u];
@@ -1150,8 +1189,11 @@ DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V
             }
         }
     } else {
-        sphere_query<true>(P, active, origin, dir, impact_id, blocker, sdist);
+        uint32_t ev_cull = 0u, ev_sphere = 0u;
+        sphere_query<true>(P, active, origin, dir, impact_id, blocker, sdist, ev_cull, ev_sphere);
         if constexpr (COUNT) {
+            cnt.ev[EV_CULL] += ev_cull; cnt.ev[EV_SPHERE] += ev_sphere;
+            cnt.ev[EV_BLOCKER] += (blocker != kNoHit) ? 1u : 0u;
             // executed tests = spheres up to and including the blocker whose id differs from the impact id
             const uint32_t n = P.n_spheres;
             const uint32_t limit = (blocker != kNoHit) ? blocker + 1u : n;
@@ -1231,7 +1273,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
     for (;;) {
         if (!unwinding) {
             // ------------------------------------------------ one node: nearest hit, shading, child rays
-            Counters cnt = {0u, 0u, 0u, 0u, 0u};
+            Counters cnt = {};
             PROF_MARK(PH_OTHER);
             PROF_KIND(depth * 2u);
             bool div_ok;
@@ -1245,7 +1287,10 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
             V3 refl_o = o, refl_d = d, refr_o = o, refr_d = d;
             if (wave_any(hit_any)) {
                 const uint32_t sidx = hit_any ? idx : 0u;  // lanes without a hit shade object 0 and discard the result
-                if constexpr (COUNT) cnt.shaded_hits += hit_any ? 1u : 0u;
+                if constexpr (COUNT) {
+                    cnt.shaded_hits += hit_any ? 1u : 0u;
+                    cnt.ev[EV_RESOLVE] += hit_any ? 1u : 0u;
+                }
                 Hit hit;
                 if (pass == PASS_CUBES) hit = cube_resolve(P, sidx, o, d, div_ok);
                 else hit = sphere_resolve(P, sidx, o, d);
@@ -1280,6 +1325,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     PROF_KIND(depth * 2u + 1u);
                     const float shadow = shadow_query<COUNT, LARGE>(P, pass, lit, hit.p, lp, light_dir, hit.id, blocker, cnt PROF_PASS);
                     if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
+                    if constexpr (COUNT) cnt.ev[EV_LIGHT] += hit_any ? 1u : 0u;
                     const float light_intensity = L.intensity * (1.0f - shadow);
                     const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
                     const Col diffuse = col_mul(col_mul(tx_a, diffuse_intensity), light_intensity);
@@ -1322,6 +1368,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     refl_o = vadd(hit.p, vscale(hit.n, 1e-2f));
                     refr_d = refract(d, hit.n, m.ior);
                     refr_o = vadd(hit.p, vscale(hit.n, 1e-3f));
+                    if constexpr (COUNT) cnt.ev[EV_CHILD] += (has_refl || has_refr) ? 1u : 0u;
                 }
                 PROF_MARK(PH_CHILDSETUP);
             }
@@ -1512,7 +1559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
     const uint32_t lane = threadIdx.x & 63u;
     Totals cnt;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) cnt.v[k] = 0ull;
+    for (int k = 0; k < 10 + EV_COUNT; ++k) cnt.v[k] = 0ull;
     // The queue is final (build_queue has completed).  Item i = the i-th traced tile in heaviest-first
     // order, then the paint groups; a workgroup takes items blockIdx.x, + gridDim.x, ...: with a grid of a
     // few times the resident workgroups the dispatcher still balances the heavy first items, the later
@@ -1599,6 +1646,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
             dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));
         }
         PROF_MARK(PH_RAYGEN);
+        if constexpr (COUNT) cnt.v[10 + EV_PRIMARY] += (active && !(skip_s && skip_c)) ? 1ull : 0ull;
         uint32_t px = 0u, hs = 0u, hc = 0u, hit_s = kNoHit, hit_c = kNoHit;
         for (uint32_t pass = PASS_SPHERES; pass <= PASS_CUBES; ++pass) {
             uint32_t hh, hi, c;
@@ -1652,7 +1700,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
     if constexpr (COUNT) {
         // wave reduction, then one atomic per wave and counter
 #pragma unroll
-        for (int k = 0; k < 10; ++k) {
+        for (int k = 0; k < 10 + EV_COUNT; ++k) {
             unsigned long long v = cnt.v[k];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -96,16 +96,22 @@ int rth_model_lower(void* hm, rt_cube* cubes, rt_sphere* spheres, rt_material* m
     });
 }
 
-// 9 * 48 * 64 * 3 bytes
-int rth_model_atlas(void* hm, uint8_t* out, uint32_t* tex_w, uint32_t* tex_h, uint32_t* sprite)
+// n_textures images of tex_w * tex_h * 3 bytes (the common layout of the model's atlases); `out` may be
+// null to query the geometry, otherwise `cap` is its capacity in bytes and is checked
+int rth_model_atlas(void* hm, uint8_t* out, size_t cap, uint32_t* n_textures, uint32_t* tex_w, uint32_t* tex_h, uint32_t* sprite)
 {
     return guarded([&] {
         HostModel* h = (HostModel*)hm;
-        std::vector<uint8_t> a = h->model.textures.to_rgb8();
-        if (out) std::copy(a.begin(), a.end(), out);
-        *tex_w = h->model.textures.tex[0].width;
-        *tex_h = h->model.textures.tex[0].height;
-        *sprite = (uint32_t)h->model.textures.tex[0].sprite_size;
+        const GameTextures::Layout l = h->model.textures.common_layout();
+        *n_textures = (uint32_t)kTextureCount;
+        *tex_w = l.width;
+        *tex_h = l.height;
+        *sprite = l.sprite;
+        if (out) {
+            std::vector<uint8_t> a = h->model.textures.to_rgb8();
+            if (cap < a.size()) throw std::runtime_error("rth_model_atlas: buffer too small");
+            std::copy(a.begin(), a.end(), out);
+        }
     });
 }
 

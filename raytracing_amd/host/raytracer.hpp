@@ -10,6 +10,7 @@
 // The only way pixels are produced is raytracer::render() -> rt_render() -> the HIP kernel.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -121,11 +122,41 @@ struct GameTextures {
         for (int i = 0; i < kTextureCount; ++i) g.tex[i] = Texture::from_rgb8(buf.data() + (size_t)i * w * h * 3, w, h, sprite);
         return g;
     }
+    // The C ABI takes ONE width/height/sprite for all atlases, while the reference keeps them per Texture
+    // (texture.rs:98-103,141-169) and indexes each with its own width (texture.rs:171-174).  Atlases of
+    // different sizes (a user's asset directory) are padded, top-left aligned, to the largest width and
+    // height: texel (x, y) keeps its coordinates, so every face lookup (x < 3*sprite, y < 4*sprite) reads
+    // what the reference reads - provided each atlas holds the whole cross layout, which is checked.
+    struct Layout { uint32_t width = 0, height = 0, sprite = 0; };
+    Layout common_layout() const
+    {
+        Layout l;
+        l.sprite = (uint32_t)tex[0].sprite_size;
+        for (const Texture& t : tex) {
+            if (t.sprite_size != tex[0].sprite_size) throw std::runtime_error("GameTextures: atlases differ in sprite size");
+            if (t.colors.size() != (size_t)t.width * t.height) throw std::runtime_error("GameTextures: an atlas holds fewer texels than width*height");
+            if (t.width < 3u * t.sprite_size || t.height < 4u * t.sprite_size)
+                throw std::runtime_error("GameTextures: an atlas is smaller than the 3x4-sprite cross layout (texture.rs:178-196 would index outside it)");
+            l.width = std::max(l.width, t.width);
+            l.height = std::max(l.height, t.height);
+        }
+        return l;
+    }
+    // kTextureCount images of layout.width x layout.height x 3 bytes (smaller atlases padded with black)
     std::vector<uint8_t> to_rgb8() const
     {
-        std::vector<uint8_t> out;
-        for (const Texture& t : tex)
-            for (const Color& c : t.colors) { out.push_back(c.r); out.push_back(c.g); out.push_back(c.b); }
+        const Layout l = common_layout();
+        std::vector<uint8_t> out((size_t)kTextureCount * l.width * l.height * 3, 0);
+        for (int i = 0; i < kTextureCount; ++i) {
+            const Texture& t = tex[i];
+            uint8_t* img = out.data() + (size_t)i * l.width * l.height * 3;
+            for (uint32_t y = 0; y < t.height; ++y)
+                for (uint32_t x = 0; x < t.width; ++x) {
+                    const Color& c = t.colors[(size_t)y * t.width + x];
+                    uint8_t* px = img + ((size_t)y * l.width + x) * 3;
+                    px[0] = c.r; px[1] = c.g; px[2] = c.b;
+                }
+        }
         return out;
     }
 };
@@ -390,10 +421,11 @@ inline LoweredScene lower_scene(const Model& data)
     for (const Sphere& sp : data.spheres) s.spheres.push_back(rt_sphere{sp.id, sp.center.c(), sp.radius, intern_material(table, sp.material)});
     if (table.empty()) table.push_back(RUBBER);
     for (const Material& m : table) s.materials.push_back(m.c());
+    const GameTextures::Layout layout = data.textures.common_layout();  // throws on atlases that cannot share one
     s.atlas = data.textures.to_rgb8();
-    s.tex_w = data.textures.tex[0].width;
-    s.tex_h = data.textures.tex[0].height;
-    s.sprite = (uint32_t)data.textures.tex[0].sprite_size;
+    s.tex_w = layout.width;
+    s.tex_h = layout.height;
+    s.sprite = layout.sprite;
     return s;
 }
 // `lights` ++ [`top_light`]  (render.rs:241-243)

@@ -24,9 +24,11 @@ for seed in range(first, first + count):
     ctx.upload(sc)
     f = sc.frame(96, 64)
     gfb, gpl = ctx.render(f, debug=True)
+    plain = ctx.render(f)  # the kernel variant that ships
     ofb, opl, ocnt, _ = orc.OracleScene(sc).render(f, debug=True, reuse_secondary=True)
     try:
         rep = assert_parity(gfb, gpl, ofb, opl, label)
+        assert (plain == gfb).all(), f"{label}: plain and debug kernels differ"
         worst = min(worst, rep["exact_fraction"])
         assert ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict(), f"{label}: ray counters differ"
     except AssertionError as e:

@@ -22,12 +22,17 @@ def colour_report(gpu, ref):
     }
 
 
-def assert_parity(gpu_fb, gpu_planes, ref_fb, ref_planes, label=""):
+def assert_parity(gpu_fb, gpu_planes, ref_fb, ref_planes, label="", exact=True):
+    """Hit planes and ray-tree hashes bit-exact; colours identical in every bit (exact=True, what the
+    kernels claim: DESIGN.md "Exactness contract") or, with exact=False, only to the north-star's bar of
+    1 LSB per channel on >= 99.9 % of pixels."""
     for k in ("hit_cube", "hit_sphere", "tree_hash"):
         bad = int((gpu_planes[k] != ref_planes[k]).sum())
         assert bad == 0, f"{label}: {k} differs from the oracle on {bad} pixels (must be bit-exact)"
     rep = colour_report(gpu_fb, ref_fb)
     assert rep["within_1lsb_fraction"] >= COLOUR_MIN_FRACTION, f"{label}: colour parity {rep}"
+    if exact:
+        assert rep["exact_fraction"] == 1.0, f"{label}: colours are not identical to the oracle's: {rep}"
     return rep
 
 

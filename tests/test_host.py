@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"librtx950.so does not export {name}"
     assert declared == set(_ffi.ABI_SYMBOLS), "ctypes table and header disagree"
-    assert _ffi.lib().rt_abi_version() == 1
+    assert _ffi.lib().rt_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():

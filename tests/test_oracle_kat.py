@@ -166,3 +166,27 @@ def test_golden_frame(oracle_mod, default_scene):
     for k in ("hit_cube", "hit_sphere", "tree_hash"):
         assert np.array_equal(planes[k], g[k])
     assert hashlib.sha256(rt.bmp_encode(fb, 270, 180)).hexdigest() == str(g["bmp_sha256"])
+
+
+def test_golden_config1_bmp(oracle_mod, default_scene):
+    """BASELINE.json config 1: the default diorama at main.rs's framebuffer size -> golden BMP.  The two BMP
+    writers (C oracle, C++ host mirror: reference src/bmp.rs:19-113) produce the committed sha256."""
+    g = np.load(os.path.join(GOLDEN, "minecraft_1080x720.npz"))
+    fb, planes, cnt, _ = oracle_mod.OracleScene(default_scene).render(default_scene.frame(1080, 720), debug=True, reuse_secondary=True)
+    assert hashlib.sha256(fb.tobytes()).hexdigest() == str(g["fb_sha256"])
+    assert np.array_equal(planes["hit_cube"], g["hit_cube"])
+    for bmp in (oracle_mod.bmp_encode(fb, 1080, 720), rt.bmp_encode(fb, 1080, 720)):
+        assert bmp[:2] == b"BM" and len(bmp) == 54 + 1080 * 720 * 3
+        assert hashlib.sha256(bmp).hexdigest() == str(g["bmp_sha256"])
+    assert list(cnt.uniq_dict().values()) == g["uniq"].tolist()
+
+
+def test_golden_config4_world(oracle_mod):
+    """BASELINE.json config 4 at its size (10 000 cubes + 256 spheres), 320x180: the committed frame."""
+    g = np.load(os.path.join(GOLDEN, "synthetic_10000c_256s_320x180.npz"))
+    s = rt.synthetic_scene()
+    fb, planes, cnt, _ = oracle_mod.OracleScene(s).render(s.frame(320, 180), debug=True, reuse_secondary=True)
+    assert np.array_equal(fb, g["fb"])
+    for k in ("hit_cube", "hit_sphere", "tree_hash"):
+        assert np.array_equal(planes[k], g[k])
+    assert list(cnt.uniq_dict().values()) == g["uniq"].tolist()
