@@ -373,7 +373,7 @@ def test_config4_world_at_size(tuned_ctx, oracle_mod, dark, scale):
     assert np.array_equal(gfb, g["fb"]) and np.array_equal(tuned_ctx.render(f), g["fb"])
     for k in ("hit_cube", "hit_sphere", "tree_hash"):
         assert np.array_equal(gpl[k], g[k]), k
-    assert (gpl["hit_sphere"] != rt.RT_NO_HIT).any() and (gpl["hit_cube"] != rt.RT_NO_HIT).mean() > 0.1
+    assert (gpl["hit_sphere"] != rt.RT_NO_HIT).any() and (gpl["hit_cube"] != rt.RT_NO_HIT).mean() > 0.05
 
 
 def test_bvh_depth_limit_falls_back_to_the_chunk_traversal(tuned_ctx, oracle_mod):
@@ -409,7 +409,7 @@ def test_config4_plain_equals_debug_at_4k(gpu_ctx):
     assert torch.equal(bufs[0], bufs[1])
     full = bufs[0].cpu().numpy().view(np.uint32)
     assert full[1, 0] == 0 and full[0, 0] == scene.sky_0rgb
-    assert (planes[0].cpu().numpy().view(np.uint32) != rt.RT_NO_HIT).mean() > 0.1
+    assert (planes[0].cpu().numpy().view(np.uint32) != rt.RT_NO_HIT).mean() > 0.05
     band = gpu_ctx.render(scene.frame(W, H, y0=1203, y1=1260))
     assert np.array_equal(band, full[1203:1260])
 
@@ -433,9 +433,9 @@ def test_config5_frame_properties_at_8k(gpu_ctx, default_scene):
     assert torch.equal(full_t, dbg_t)
     full = full_t.cpu().numpy().view(np.uint32)
     a, b = gpu_ctx.row_extent(f)
-    assert 0 < a < b < H
+    assert 0 < a < b <= H  # from this angle the platform's near corner leaves the frame at the bottom
     sky = np.full((W,), default_scene.sky_0rgb, dtype=np.uint32)
-    assert full[1, 0] == 0 and (full[0] == sky).all() and (full[a - 1] == sky).all() and (full[b:] == sky).all()
+    assert full[1, 0] == 0 and (full[0] == sky).all() and (full[2:a] == sky).all() and (full[b:] == sky).all()
     assert (full[a:b] != default_scene.sky_0rgb).any()
     for y0, y1 in ((0, 540), (2153, 2171), (3780, 4320)):
         assert np.array_equal(gpu_ctx.render(default_scene.frame(W, H, y0=y0, y1=y1, camera=cam)), full[y0:y1]), (y0, y1)
