@@ -13,10 +13,13 @@ timed region, overlapped with the rendering of the next frame.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  value = unique rays of the frame (nearest-hit + shadow list traversals,
-SURVEY.md section 8(d)) x K / max-over-ranks wall time.  roofline: algorithmic FP32 ops
-(26/cube test + 25/sphere test + 60 x lights/shaded hit) of rank 0's launch / its HIP-event time,
-against the 157.3 TFLOP/s FP32 vector peak.  cpu_baseline: the oracle (reference algorithm,
-per-light re-casting, all host threads) on a bounded row sample of the same frame, N=1 only.
+SURVEY.md section 8(d)) x K / max-over-ranks wall time.  roofline: the FP32 operations rank 0's launch
+EXECUTES (events counted by the kernel's counting variant, rt_count_executed, priced per event: EVENT_FLOPS
+below and DESIGN.md) / the launch's HIP-event time, against the 157.3 TFLOP/s FP32 vector peak; the
+reference's brute-force operation count over the same time is reported beside it as algorithmic_speedup
+(the cull proves most of those tests away, so that ratio is not an efficiency).  cpu_baseline: the oracle
+(reference algorithm, per-light re-casting, the host cores this job may use) on a bounded row sample of the
+same frame, N=1 only.
 """
 import argparse
 import json
@@ -49,24 +52,43 @@ def algorithmic_flops(c, n_lights):
     return 26.0 * c.cube_tests + 25.0 * c.sphere_tests + 60.0 * n_lights * c.shaded_hits
 
 
-def profile_field(workload, field):
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(workload, {}).get(field)
-    except (OSError, ValueError):
-        return None
+# FP32 operations per executed event (rt_exec_counters), counted from the source of
+# raytracing_amd/csrc/rtx950_kernels.hip with an FMA as 2, a correctly rounded division or square root as 1
+# (they take ~10 instructions each) and compares/min/max/abs as 1; integer, control and data movement are
+# not counted.  Derivation per event in DESIGN.md, "Roofline".
+EVENT_FLOPS = {
+    "cull_tests": 33,        # cull_test: 3 axes x (2 FMA + add + 2 FMA + |g| > l) + 3 abs
+    "chunk_tests": 39,       # chunk_test: 3 axes x (2 FMA + add + 3 FMA + compare) + 3 abs
+    "candidate_evals": 31,   # cube_slab_approx (9 FMA, max3, min3) + gap, 2 decisions, distance select, fold
+    "exact_evals": 26,       # cube_exact = Cube::ray_intersect's slab test
+    "bvh_steps": 52,         # two box_slab (9 FMA + max3 + min3 + gap + compare each) + ordering compares
+    "sphere_evals": 25,      # sphere_exact
+    "queries": 37,           # ray_pre (3 rcp, 3 mul, error bound) + cull_pre (moments, radii)
+    "light_iterations": 60,  # Phong fold per light
+    "resolved_hits": 64,     # cube_distance (3 refined reciprocals, 3 shared divisions), hit point, face tests, uv
+    "blockers": 65,          # the blocker's cube_distance + distance2 + shadow term
+    "child_setups": 60,      # reflect + normalize + refract + two origins
+    "primary_rays": 40,      # ray generation: two normalisations and the change of basis
+}
 
 
-def traffic_from_profile(workload):
-    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/traffic.json, written by tools/summarize_pmc.py: 2 x FETCH_SIZE KB + WRITE_SIZE KB
-    as MI355X_MICROARCH.md prescribes for gfx950); None when no pass is on file for the workload."""
+def executed_flops(ex):
+    d = ex.as_dict()
+    return float(sum(EVENT_FLOPS[k] * d[k] for k in EVENT_FLOPS))
+
+
+def profile_entry(workload, kernel):
+    """The committed rocprofv3 PMC passes of this command (profiles/traffic.json, written by
+    tools/summarize_pmc.py), keyed by workload and kernel instantiation; {} when none is on file."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        return t.get(workload, {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
-        return None
+        return {}
+    e = t.get(workload, {})
+    if "kernels" in e:
+        return e["kernels"].get(kernel, {})
+    return {}
 
 
 def make_scene(rt, kind, kwargs):
@@ -82,7 +104,12 @@ def cpu_baseline(scene, width, height, target_s, max_threads):
     import oracle as orc
     O = orc.OracleScene(scene)
     frame = scene.frame(width, height)
-    threads = max(1, min(max_threads, len(os.sched_getaffinity(0))))
+    allowed = len(os.sched_getaffinity(0))
+    # 0 = every core this job may use: the affinity mask, capped by the box's per-job share when it states
+    # one (the GPU box exports OMP_NUM_THREADS = its CPU share per GPU while nproc shows the whole machine)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    threads = max_threads if max_threads > 0 else (min(allowed, share) if share > 0 else allowed)
+    threads = max(1, min(threads, allowed))
     probe_step = max(1, height // 24)
     t0 = time.perf_counter()
     _, _, cnt, used = O.render(frame, reuse_secondary=False, row_step=probe_step, threads=threads)
@@ -105,6 +132,8 @@ def cpu_baseline(scene, width, height, target_s, max_threads):
         "value": rays / secs / 1e6,
         "unit": "Mrays/s",
         "cores": int(used),
+        "host_logical_cores": os.cpu_count(),
+        "cores_allowed": allowed,
         "kind": "port",
         "sample": f"{what}: {rays} reference rays in {secs:.2f} s, oracle literal mode (per-light re-casting), pthreads over rows",
         "seconds": secs,
@@ -120,7 +149,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="minecraft_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU baseline sample; 0 disables it")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU baseline; 0 = all cores this job may use (affinity mask, capped by OMP_NUM_THREADS "
+                         "when the box sets it as the job's CPU share)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (one library context and stream each: the next frame starts under the current "
                          "frame's slowest tiles); 0 = the default: 2 at N = 1, 3 per rank at N > 1; 1 = strictly one frame at a time")
@@ -198,7 +229,8 @@ def main():
     grid_limit = args.grid_limit if args.grid_limit >= 0 else (12288 if inflight > 1 else 0)
     for c in ctxs:
         c.set_grid_limit(grid_limit)
-    pipe = FramePipeline(fg, lambda buf, slot: ctxs[slot].render_device(frame, buf.data_ptr(), n_parts=world, part=rank), streams) if piped else None
+    pipe = FramePipeline(fg, lambda buf, slot: ctxs[slot].render_device(frame, buf.data_ptr(), n_parts=world, part=rank), streams,
+                         time_every=max(1, args.time_every)) if piped else None
 
     orbit = bool(kwargs.get("orbit"))
     state = {"cam": scene.camera, "n": 0}
@@ -237,6 +269,8 @@ def main():
     for c in ctxs:
         c.enable_timing(max(1, args.time_every))
         c.kernel_time_ms()  # drop anything recorded so far
+    if pipe is not None:
+        pipe.gather_stats()
     if world > 1:
         dist.barrier()
     sync()
@@ -265,6 +299,17 @@ def main():
         kern_all = [kern_ms]
 
     # ---- accounting (outside the timed region)
+    gather_ms, gather_n, sent_bytes = (pipe.gather_stats() if pipe is not None else (0.0, 0, 0))
+    if world > 1:
+        g = torch.tensor([gather_ms, float(sent_bytes)], dtype=torch.float64, device=cdev)
+        g_list = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(g_list, g)
+        gather_all = [float(x[0].item()) for x in g_list]
+        sent_all = [int(x[1].item()) for x in g_list]
+    else:
+        gather_all, sent_all = [gather_ms], [sent_bytes]
+
+    ok = True
     result = None
     if rank == 0:
         if orbit:
@@ -283,13 +328,27 @@ def main():
             if not torch.equal(whole, last):
                 bad = int((whole != last).sum().item())
                 print(f"bench.py: the frame gathered from {world} rank(s) differs from the single-GPU frame in {bad} pixels", file=sys.stderr)
-                sys.exit(3)
-        total = ctx.count_rays(frame)
-        mine = ctx.count_rays(frame, n_parts=world, part=0) if world > 1 else total
+                ok = False
+    if world > 1:
+        # every rank learns the verdict before any of them leaves (a lone exit would strand the others in the barrier)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if not ok:
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
+
+    if rank == 0:
+        total, total_ex = ctx.count_executed(frame)
+        mine, mine_ex = ctx.count_executed(frame, n_parts=world, part=0) if world > 1 else (total, total_ex)
         rays_uniq, rays_ref = total.rays, total.ref_rays
         ms_per_step = elapsed / args.steps * 1e3
-        flops_launch = algorithmic_flops(mine, n_lights)
-        achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        kernel = ctx.kernel_name()
+        flops_ref = algorithmic_flops(mine, n_lights)     # what the reference's brute force would do for this launch
+        flops_exec = executed_flops(mine_ex)              # what the kernel does
+        achieved_tf = flops_exec / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        prof = profile_entry(args.workload, kernel)
         result = {
             "metric": "Mrays/s (primary+shadow+secondary, unique rays)",
             "value": rays_uniq * args.steps / elapsed / 1e6,
@@ -316,17 +375,31 @@ def main():
             },
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic_from_profile(args.workload),
-                "kernel": "render_kernel<false,false>", "kernel_avg_ms": kern_ms, "launches_timed": kern_n, "timed_every": max(1, args.time_every), "launches_overlap": inflight > 1,
-                "algorithmic_flops_per_launch": flops_launch,
+                "frac": achieved_tf / PEAK_FP32_TFLOPS,
+                "traffic": prof.get("hbm_bytes_per_launch"),
+                "kernel": kernel, "kernel_avg_ms": kern_ms, "launches_timed": kern_n, "timed_every": max(1, args.time_every), "launches_overlap": inflight > 1,
+                "executed_flops_per_launch": flops_exec,
+                "executed_events_per_launch": mine_ex.as_dict(),
+                # the same executed operations against the ceiling of one plain (unpacked, non-FMA) op per lane and clock
                 "frac_of_nonfma_lane_op_ceiling": achieved_tf / PEAK_LANE_OPS_T,
-                # executed view from the committed rocprofv3 PMC pass of this command (profiles/traffic.json)
-                "valu_busy_frac_pmc": profile_field(args.workload, "valu_busy_frac"),
-                "valu_insts_per_launch_pmc": profile_field(args.workload, "valu_insts_per_launch"),
-                "note": "algorithmic FP32 ops of the reference's brute-force walk: 26/ray-cube test + 25/ray-sphere test + 60*lights/shaded hit (SURVEY 8d), rank 0's launch; the kernel proves most tests fail without executing them, so frac can exceed 1 (executed view: valu_busy_frac_pmc)",
+                # the reference's brute-force walk of the same launch over the same time: not an efficiency (the cull,
+                # the slab filter and the tile classification prove most of those tests away), a speed-up of the method
+                "algorithmic_flops_per_launch": flops_ref,
+                "algorithmic_tflops_equivalent": flops_ref / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
+                "algorithmic_speedup": flops_ref / flops_exec if flops_exec > 0 else None,
+                # executed view from the committed rocprofv3 PMC passes of this command and kernel (profiles/traffic.json)
+                "pmc": {k: prof.get(k) for k in ("valu_insts_per_launch", "valu_busy_frac", "active_lanes_per_inst", "lane_ops_per_s", "frac_of_lane_op_ceiling", "source")} if prof else None,
+                "note": "achieved = FP32 operations the launch executes (rt_count_executed events x EVENT_FLOPS, an FMA as 2, a division as 1) / its HIP-event duration; "
+                        "algorithmic_* = the reference's brute force (26/ray-cube test + 25/ray-sphere test + 60*lights/shaded hit, SURVEY 8d) for comparison",
             },
         }
         result["config"]["settle_frames"] = settle
+        if world > 1:
+            result["config"]["exchange"] = {
+                "gather_ms_per_rank": gather_all, "gathers_timed": gather_n, "bytes_sent_per_frame_per_rank": sent_all,
+                "bytes_into_gpu0_per_frame": int(sum(sent_all)),
+                "note": "gather_ms: events on the frame's stream around dist.gather (+ rank 0's sky fill and row scatter), i.e. from the end of the rank's render to the end of its exchange",
+            }
         if pipe is not None or inflight > 1:
             result["config"]["grid_limit"] = grid_limit if grid_limit > 0 else 32768
             result["config"]["frame_check"] = "gathered frame identical to the frame rendered whole on GPU0 (checked after the timed region)"
@@ -334,9 +407,8 @@ def main():
             cb = cpu_baseline(scene, W, H, args.cpu_seconds, args.cpu_threads)
             result["cpu_baseline"] = cb
             result["config"]["gpu_over_cpu_reference_accounting"] = (rays_ref * args.steps / elapsed / 1e6) / cb["value"]
-        if world == 1 and inflight > 1:
-            # The same workload strictly one frame at a time (one context, one stream), measured apart: how long a
-            # frame takes from launch to completion, and the render kernel's duration alone on the GPU.
+        if world == 1:
+            # ---- latency side of the same workload, measured apart (one context, one stream)
             if orbit:
                 frame.camera = scene.camera
             ctx.set_grid_limit(0)  # the library's default, which is the best for one frame at a time
@@ -352,11 +424,54 @@ def main():
             dt = (time.perf_counter() - t1) / args.steps
             solo_ms, _ = ctx.kernel_time_ms()
             ctx.enable_timing(False)
-            ctx.set_grid_limit(grid_limit)
             result["config"]["one_frame_in_flight"] = {"ms_per_step": dt * 1e3, "value": rays_uniq / dt / 1e6, "unit": "Mrays/s",
                                                        "kernel_avg_ms": solo_ms,
-                                                       "roofline_frac": (flops_launch / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if solo_ms > 0 else None,
+                                                       "roofline_frac": (flops_exec / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if solo_ms > 0 else None,
                                                        "note": "--inflight 1 makes this the timed mode"}
+            # a frame from launch to completion with the host waiting for it (what an interactive host sees)
+            lat = []
+            for _ in range(50):
+                t1 = time.perf_counter()
+                ctx.render_device(frame, out.data_ptr())
+                ctx.sync()
+                lat.append(time.perf_counter() - t1)
+            lat.sort()
+            result["single_frame_latency_ms"] = lat[len(lat) // 2] * 1e3
+            # the first frame after a camera jump: the queue order comes from the previous launch's tile costs, so
+            # a new view starts with a stale order (and a new set of traced tiles)
+            jumps, steady = [], []
+            cam_a = scene.camera
+            for k in range(12):
+                cam_b = rt.rotate_cam(cam_a, 0.9 + 0.37 * k, 0.11 * ((k % 3) - 1))
+                f2 = scene.frame(W, H, camera=cam_b)
+                t1 = time.perf_counter()
+                ctx.render_device(f2, out.data_ptr())
+                ctx.sync()
+                jumps.append(time.perf_counter() - t1)
+                for _ in range(3):
+                    ctx.render_device(f2, out.data_ptr())
+                ctx.sync()
+                t1 = time.perf_counter()
+                ctx.render_device(f2, out.data_ptr())
+                ctx.sync()
+                steady.append(time.perf_counter() - t1)
+                cam_a = cam_b
+            result["config"]["camera_jump"] = {"first_frame_ms": sum(jumps) / len(jumps) * 1e3, "same_view_steady_ms": sum(steady) / len(steady) * 1e3,
+                                               "note": "12 jumps to unrelated views, one frame at a time, host waits per frame"}
+            # rt_render, the reference's synchronous render(): kernels + the single read-back over PCIe
+            def timed_rt_render(target):
+                ctx.render(frame, out=target)
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    ctx.render(frame, out=target)
+                return (time.perf_counter() - t1) / 10 * 1e3
+            import numpy as np
+            pageable = np.empty((H, W), dtype=np.uint32)
+            pinned = rt.PinnedFrame(H, W)
+            result["config"]["rt_render_ms"] = {"pageable_host_memory": timed_rt_render(pageable), "pinned_host_memory (rt_host_alloc)": timed_rt_render(pinned.array),
+                                                "bytes_read_back": H * W * 4, "note": "synchronous like the reference's render(): launches + D2H copy + wait; never `value`"}
+            pinned.close()
+            ctx.set_grid_limit(grid_limit)
         if world == 1 and args.extra:
             extra = {}
             for name in ("minecraft_1080p", "minecraft_water_4k"):

@@ -343,6 +343,11 @@ int rt_set_tuning(rt_ctx* ctx, int key, double value);
  * reference-identical rounding of normalize() and of the slab quotients rests on it). */
 int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t* out_mismatches, uint64_t* out_cases);
 
+/* Name of the render kernel instantiation that rt_render / rt_render_device launch for the uploaded scene,
+ * e.g. "render_kernel<false,false,false,false>" (template arguments: debug planes, counters, long cube list,
+ * dark-material test), as it appears in a rocprofv3 kernel trace.  No reference counterpart. */
+const char* rt_kernel_name(const rt_ctx* ctx);
+
 /* Raw HIP stream of the context as an opaque pointer (hipStream_t), for hosts that order their
  * own work (e.g. an RCCL gather) after the render.  No reference counterpart. */
 int rt_get_stream(rt_ctx* ctx, void** out_hip_stream);

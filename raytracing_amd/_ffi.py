@@ -157,6 +157,7 @@ ABI_SYMBOLS = {
     "rt_frame_row_extent": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_count_executed": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_uint32, C.c_uint32, C.POINTER(Counters), C.POINTER(ExecCounters)]),
     "rt_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "rt_kernel_name": (C.c_char_p, [C.c_void_p]),
     "rt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "rt_host_free": (C.c_int, [C.c_void_p]),
     "rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_void_p]),

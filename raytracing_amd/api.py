@@ -261,6 +261,10 @@ class Context:
         self._check(self._lib.rt_frame_row_extent(self._ctx, C.byref(frame), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def kernel_name(self) -> str:
+        """rt_kernel_name: the render kernel instantiation the uploaded scene selects."""
+        return (self._lib.rt_kernel_name(self._ctx) or b"").decode()
+
     def stream(self) -> int:
         s = C.c_void_p()
         self._check(self._lib.rt_get_stream(self._ctx, C.byref(s)))

@@ -1306,6 +1306,14 @@ int rt_render_multi(rt_ctx* const* ctxs, uint32_t n_ctx, const rt_frame* frame, 
     return rt_gather_bands(ctxs, n_ctx, parts.data(), w, s1 - s0, d_frame_on_ctx0 + (size_t)(s0 - frame->y0) * w, out_bytes_moved);
 }
 
+const char* rt_kernel_name(const rt_ctx* ctx)
+{
+    if (!ctx || !ctx->has_scene) return "";
+    const bool large = ctx->base.n_chunks > 0u, dark = ctx->base.dark_materials != 0u;  // launch_render's choice
+    if (large) return dark ? "render_kernel<false,false,true,true>" : "render_kernel<false,false,true,false>";
+    return dark ? "render_kernel<false,false,false,true>" : "render_kernel<false,false,false,false>";
+}
+
 int rt_get_stream(rt_ctx* ctx, void** out_hip_stream)
 {
     if (!ctx || !out_hip_stream) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");

@@ -170,10 +170,15 @@ class FramePipeline:
     streams wrapping the library's: torch.cuda.ExternalStream(ctx.stream())).  On a CPU device (gloo
     tests, render_streams=None) everything runs in program order."""
 
-    def __init__(self, gather: FrameGather, render, render_streams=None):
+    def __init__(self, gather: FrameGather, render, render_streams=None, time_every=0):
         self.g, self.render = gather, render
         self.depth = len(gather.locals)
         self.n = 0
+        # time_every = k > 0: every k-th frame's exchange (collective + rank 0's fill and scatter) is bracketed
+        # by events on its slot's stream (gather_stats)
+        self.time_every = int(time_every)
+        self._timed = []
+        self.last_window_rows = 0
         self.cuda = render_streams is not None
         if self.cuda:
             if len(render_streams) != self.depth or len(set(s.cuda_stream for s in render_streams)) != self.depth:
@@ -185,12 +190,32 @@ class FramePipeline:
         slot = self.n % self.depth
         self.render(self.g.locals[slot], slot)
         if self.cuda:
+            timed = self.time_every > 0 and self.n % self.time_every == 0
             with torch.cuda.stream(self.render_streams[slot]):
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 self.g.gather(slot, extent, sky)
+                if timed:
+                    e1.record()
+                    self._timed.append((e0, e1))
         else:
             self.g.gather(slot, extent, sky)
+        a, b, _, _ = message_window(self.g.rows, self.g.world, None if extent is None else (int(extent[0]), int(extent[1])), max_rows=self.g.max_rows)
+        self.last_window_rows = b - a
         self.n += 1
         return slot
+
+    def gather_stats(self):
+        """(average ms of the timed exchanges since the last call, their number, bytes this rank sent per
+        frame in the last frame's message window).  Waits for the timed frames."""
+        ms = []
+        for e0, e1 in self._timed:
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        self._timed = []
+        sent = 0 if self.g.rank == 0 else self.last_window_rows * self.g.width * 4
+        return (sum(ms) / len(ms) if ms else 0.0), len(ms), sent
 
     def drain(self):
         """Host wait until every submitted frame has reached rank 0."""

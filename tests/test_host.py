@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "rtx950.h")).read()
     declared = set(re.findall(r"^\s*(?:int|uint32_t|const char\*)\s+(rt_[a-z_0-9]+)\s*\(", header, flags=re.M))
+    assert "rt_kernel_name" in declared and "rt_render_device_noalloc" in declared and "rt_render_multi" in declared
     assert len(declared) >= 15
     lib = C.CDLL(_ffi.LIB_PATH)
     for name in declared:
@@ -142,3 +143,31 @@ def test_part_rows_matches_python_partition():
         for n in (1, 2, 3, 8):
             for p in range(n):
                 assert rt.part_rows(rows, n, p) == len(rt.part_row_indices(rows, n, p))
+
+
+def test_atlases_of_different_sizes(tmp_path):
+    """The reference keeps a width and height per Texture (src/texture.rs:98-103,141-169); the C ABI takes one
+    for all nine.  A user asset directory whose PNGs differ in size is padded to a common size (texel
+    coordinates unchanged, so every face lookup reads what the reference reads); an atlas smaller than the
+    3x4-sprite cross layout is refused instead of read out of bounds."""
+    from PIL import Image
+    src = os.path.join(ROOT, "tests", "golden", "imgs")
+    names = ["dirt", "stone", "moss", "water", "obsidian", "portal", "netherrack", "magma", "gold"]
+    d = tmp_path / "assets"
+    d.mkdir()
+    for n in names:
+        img = Image.open(os.path.join(src, n + ".png")).convert("RGBA")
+        if n == "gold":  # a larger canvas, the original in its top-left corner
+            big = Image.new("RGBA", (64, 80), (9, 9, 9, 255))
+            big.paste(img, (0, 0))
+            img = big
+        img.save(d / (n + ".png"))
+    s = rt.default_scene(assets=str(d) + "/")
+    base = rt.default_scene()
+    assert s.atlas.shape == (9, 80, 64, 3) and (s.tex_w, s.tex_h, s.sprite) == (64, 80, 16)
+    assert np.array_equal(s.atlas[:, :64, :48], base.atlas)
+    assert (s.atlas[:8, 64:, :] == 0).all() and (s.atlas[8, 70, 60] == 9).all()
+    Image.open(os.path.join(src, "magma.png")).convert("RGBA").crop((0, 0, 40, 64)).save(d / "magma.png")
+    with pytest.raises(RuntimeError) as e:
+        rt.default_scene(assets=str(d) + "/")
+    assert "cross layout" in str(e.value)
