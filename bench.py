@@ -161,6 +161,10 @@ def main():
     ap.add_argument("--grid-limit", type=int, default=-1,
                     help="rt_set_grid_limit of every context; -1 = 12288 with frames in flight (two render kernels share the GPU), "
                          "the library's default (32768) with one")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling runs (tools/profile_workloads.sh): only run-in, warm-up, the timed region and the counting launch; "
+                         "no CPU baseline and none of the side measurements, so that a rocprofv3 trace of the command holds the timed "
+                         "launches and nothing else of the render kernel")
     ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
     args = ap.parse_args()
 
@@ -403,11 +407,11 @@ def main():
         if pipe is not None or inflight > 1:
             result["config"]["grid_limit"] = grid_limit if grid_limit > 0 else 32768
             result["config"]["frame_check"] = "gathered frame identical to the frame rendered whole on GPU0 (checked after the timed region)"
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and not args.lean:
             cb = cpu_baseline(scene, W, H, args.cpu_seconds, args.cpu_threads)
             result["cpu_baseline"] = cb
             result["config"]["gpu_over_cpu_reference_accounting"] = (rays_ref * args.steps / elapsed / 1e6) / cb["value"]
-        if world == 1:
+        if world == 1 and not args.lean:
             # ---- latency side of the same workload, measured apart (one context, one stream)
             if orbit:
                 frame.camera = scene.camera
@@ -472,7 +476,7 @@ def main():
                                                 "bytes_read_back": H * W * 4, "note": "synchronous like the reference's render(): launches + D2H copy + wait; never `value`"}
             pinned.close()
             ctx.set_grid_limit(grid_limit)
-        if world == 1 and args.extra:
+        if world == 1 and args.extra and not args.lean:
             extra = {}
             for name in ("minecraft_1080p", "minecraft_water_4k"):
                 k2, kw2, w2, h2 = WORKLOADS[name]

@@ -191,6 +191,7 @@ extern "C" {
     pub fn rt_count_executed(ctx: *mut rt_ctx, frame: *const rt_frame, n_parts: u32, part: u32, out: *mut rt_counters, exec: *mut rt_exec_counters) -> c_int;
     pub fn rt_set_tuning(ctx: *mut rt_ctx, key: c_int, value: f64) -> c_int;
     pub fn rt_kernel_name(ctx: *const rt_ctx) -> *const c_char;
+    pub fn rt_debug_tile_costs(ctx: *mut rt_ctx, out: *mut u32, cap: usize, out_tiles: *mut usize) -> c_int;
     pub fn rt_host_alloc(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
     pub fn rt_host_free(ptr: *mut c_void) -> c_int;
     pub fn rt_render_device_noalloc(ctx: *mut rt_ctx, frame: *const rt_frame, d_out_0rgb: *mut u32) -> c_int;

@@ -348,6 +348,12 @@ int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t*
  * dark-material test), as it appears in a rocprofv3 kernel trace.  No reference counterpart. */
 const char* rt_kernel_name(const rt_ctx* ctx);
 
+/* Diagnostic, no counterpart in the reference: cycles each 8x8 tile of the context's last launch took
+ * (0 = not traced), in the launch's tile grid (ceil(width/8) columns, two tile rows per 16-row block of the
+ * part); the library uses them only to order the next launch's queue.  Copies min(cap, tiles) words after
+ * waiting for the stream; *out_tiles = tiles of the last launch's grid buffer. */
+int rt_debug_tile_costs(rt_ctx* ctx, uint32_t* out, size_t cap, size_t* out_tiles);
+
 /* Raw HIP stream of the context as an opaque pointer (hipStream_t), for hosts that order their
  * own work (e.g. an RCCL gather) after the render.  No reference counterpart. */
 int rt_get_stream(rt_ctx* ctx, void** out_hip_stream);

@@ -158,6 +158,7 @@ ABI_SYMBOLS = {
     "rt_count_executed": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_uint32, C.c_uint32, C.POINTER(Counters), C.POINTER(ExecCounters)]),
     "rt_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "rt_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "rt_debug_tile_costs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "rt_host_free": (C.c_int, [C.c_void_p]),
     "rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_void_p]),

@@ -261,6 +261,14 @@ class Context:
         self._check(self._lib.rt_frame_row_extent(self._ctx, C.byref(frame), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def tile_costs(self):
+        """rt_debug_tile_costs: cycles per 8x8 tile of the last launch (uint32 array, launch tile grid order)."""
+        n = C.c_size_t()
+        self._check(self._lib.rt_debug_tile_costs(self._ctx, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        self._check(self._lib.rt_debug_tile_costs(self._ctx, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
+        return out
+
     def kernel_name(self) -> str:
         """rt_kernel_name: the render kernel instantiation the uploaded scene selects."""
         return (self._lib.rt_kernel_name(self._ctx) or b"").decode()

@@ -1306,6 +1306,18 @@ int rt_render_multi(rt_ctx* const* ctxs, uint32_t n_ctx, const rt_frame* frame, 
     return rt_gather_bands(ctxs, n_ctx, parts.data(), w, s1 - s0, d_frame_on_ctx0 + (size_t)(s0 - frame->y0) * w, out_bytes_moved);
 }
 
+int rt_debug_tile_costs(rt_ctx* ctx, uint32_t* out, size_t cap, size_t* out_tiles)
+{
+    if (!ctx || !out_tiles) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
+    ENTER_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t tiles = ctx->own.cost_cap ? ctx->own.cost_cap - 1 : 0;
+    *out_tiles = tiles;
+    const size_t n = cap < tiles ? cap : tiles;
+    if (out && n) HIP_TRY(ctx, hipMemcpy(out, ctx->own.cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 const char* rt_kernel_name(const rt_ctx* ctx)
 {
     if (!ctx || !ctx->has_scene) return "";
