@@ -652,7 +652,10 @@ DEV CullPre cull_pre(bool active, V3 o, V3 d, bool wild, float bound_max, float 
 {
     CullPre c;
     const unsigned long long am = wave_ballot(active);
-    const uint32_t ref = am ? (uint32_t)__builtin_ctzll(am) : 0u;
+    // The reference lane: any active lane will do; one near the middle of the 8x8 tile (pixel (3,3), else (4,4),
+    // else the first active lane from row 2 on) halves the radii of a full tile against its corner lane.
+    const unsigned long long am_mid = am >> 20;
+    const uint32_t ref = ((am >> 27) & 1ull) ? 27u : (((am >> 36) & 1ull) ? 36u : (am_mid ? 20u + (uint32_t)__builtin_ctzll(am_mid) : (am ? (uint32_t)__builtin_ctzll(am) : 0u)));
     c.all = wave_any(active && wild);
     // moments (only ever compared against bounds with slack: FMA is fine here)
     const float wxy = __builtin_fmaf(o.x, d.y, -(o.y * d.x)), wyz = __builtin_fmaf(o.y, d.z, -(o.z * d.y)), wzx = __builtin_fmaf(o.z, d.x, -(o.x * d.z));
