@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--grid-limit", type=int, default=-1,
                     help="rt_set_grid_limit of every context; -1 = 12288 with frames in flight (two render kernels share the GPU), "
                          "the library's default (32768) with one")
+    ap.add_argument("--heavy-class", type=int, default=-1,
+                    help="rt_set_tuning(RT_TUNE_HEAVY_CLASS) of every context (tiles of this cost class and above get a three-wave "
+                         "workgroup; 8 = none); -1 = the library's default")
     ap.add_argument("--lean", action="store_true",
                     help="profiling runs (tools/profile_workloads.sh): only run-in, warm-up, the timed region and the counting launch; "
                          "no CPU baseline and none of the side measurements, so that a rocprofv3 trace of the command holds the timed "
@@ -233,6 +236,8 @@ def main():
     grid_limit = args.grid_limit if args.grid_limit >= 0 else (12288 if inflight > 1 else 0)
     for c in ctxs:
         c.set_grid_limit(grid_limit)
+        if args.heavy_class >= 0:
+            c.set_tuning(rt.RT_TUNE_HEAVY_CLASS, args.heavy_class)
     pipe = FramePipeline(fg, lambda buf, slot: ctxs[slot].render_device(frame, buf.data_ptr(), n_parts=world, part=rank), streams,
                          time_every=max(1, args.time_every)) if piped else None
 

@@ -14,6 +14,7 @@ pub const RT_TUNE_SHADOW_LIST: c_int = 2;
 pub const RT_TUNE_DARK_KERNEL: c_int = 3;
 pub const RT_TUNE_FILL_MEMSET: c_int = 4;
 pub const RT_TUNE_BVH_DEPTH_LIMIT: c_int = 5;
+pub const RT_TUNE_HEAVY_CLASS: c_int = 6;
 pub const RT_MAX_DEPTH: u32 = 3; // src/render.rs:83
 pub const RT_MAX_LIGHTS: u32 = 16;
 pub const RT_TEXTURE_NONE: i32 = -1; // `texture: None`, src/material.rs:6
@@ -191,6 +192,7 @@ extern "C" {
     pub fn rt_count_executed(ctx: *mut rt_ctx, frame: *const rt_frame, n_parts: u32, part: u32, out: *mut rt_counters, exec: *mut rt_exec_counters) -> c_int;
     pub fn rt_set_tuning(ctx: *mut rt_ctx, key: c_int, value: f64) -> c_int;
     pub fn rt_kernel_name(ctx: *const rt_ctx) -> *const c_char;
+    pub fn rt_debug_status(ctx: *mut rt_ctx, out_word: *mut u32) -> c_int;
     pub fn rt_debug_tile_costs(ctx: *mut rt_ctx, out: *mut u32, cap: usize, out_tiles: *mut usize) -> c_int;
     pub fn rt_host_alloc(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
     pub fn rt_host_free(ptr: *mut c_void) -> c_int;

@@ -188,6 +188,18 @@ typedef enum rt_tuning {
                                    "direct light is exactly black" test.  Next rt_scene_upload             */
     RT_TUNE_FILL_MEMSET = 4,    /* 0 (default) / 1: sky pixels are written by a fill ahead of the launches
                                    instead of by build_queue.  Next render call                            */
+    RT_TUNE_HEAVY_CLASS = 6,    /* -1 (default, automatic) or 0..8: the tiles of a plain frame whose cost class in the
+                                   context's previous launch was at least this (class c = 8 K << c cycles and up;
+                                   at most about 512 tiles, heaviest classes first) are traced by a side kernel on
+                                   the context's second stream - a workgroup of three waves per tile, concurrent
+                                   with the frame's other launches and joined to the context's stream before the
+                                   call returns - instead of one wave each: shortens a frame that is bound by
+                                   its slowest tile (one frame at a time, small frames, the parts of an N-GPU
+                                   split), costs about 12 us of event traffic per frame, and should stay off
+                                   where several contexts keep frames in flight (more streams than hardware
+                                   queues).  8 = never.  Automatic: class 5 for the synchronous rt_render of
+                                   frames of up to 65536 tiles, never for the asynchronous entry points.
+                                   Results do not depend on it.  Next render call                            */
     RT_TUNE_BVH_DEPTH_LIMIT = 5 /* deepest BVH the per-lane walk takes (1..28, default 28 = the walk's stack);
                                    a deeper tree sends every wave through the chunk traversal.  28 levels
                                    cannot be exceeded by a real list, so tests lower it.  Next rt_scene_upload */
@@ -344,9 +356,15 @@ int rt_set_tuning(rt_ctx* ctx, int key, double value);
 int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t* out_mismatches, uint64_t* out_cases);
 
 /* Name of the render kernel instantiation that rt_render / rt_render_device launch for the uploaded scene,
- * e.g. "render_kernel<false,false,false,false>" (template arguments: debug planes, counters, long cube list,
- * dark-material test), as it appears in a rocprofv3 kernel trace.  No reference counterpart. */
+ *  e.g. "render_kernel<false,false,false,false>" (template arguments: debug planes, counters, long cube list,
+ * dark-material test), as it appears in a rocprofv3 kernel trace; with RT_TUNE_HEAVY_CLASS in effect
+ * render_heavy_kernel<long list, dark-material test> runs beside it.  No reference counterpart. */
 const char* rt_kernel_name(const rt_ctx* ctx);
+
+/* Diagnostic, no counterpart in the reference: 0 unless a wave of a heavy tile's workgroup (RT_TUNE_HEAVY_CLASS)
+ * gave up waiting for its partners in one of the context's launches (never expected; the frame is then
+ * wrong).  Waits for the stream. */
+int rt_debug_status(rt_ctx* ctx, uint32_t* out_word);
 
 /* Diagnostic, no counterpart in the reference: cycles each 8x8 tile of the context's last launch took
  * (0 = not traced), in the launch's tile grid (ceil(width/8) columns, two tile rows per 16-row block of the

@@ -30,6 +30,7 @@ RT_TUNE_SHADOW_LIST = 2
 RT_TUNE_DARK_KERNEL = 3
 RT_TUNE_FILL_MEMSET = 4
 RT_TUNE_BVH_DEPTH_LIMIT = 5
+RT_TUNE_HEAVY_CLASS = 6
 
 
 class Vec3(C.Structure):
@@ -158,6 +159,7 @@ ABI_SYMBOLS = {
     "rt_count_executed": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_uint32, C.c_uint32, C.POINTER(Counters), C.POINTER(ExecCounters)]),
     "rt_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "rt_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "rt_debug_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rt_debug_tile_costs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "rt_host_free": (C.c_int, [C.c_void_p]),

@@ -231,9 +231,12 @@ class Context:
         """rt_set_tuning (keys: _ffi.RT_TUNE_*)."""
         self._check(self._lib.rt_set_tuning(self._ctx, int(key), float(value)))
 
+    # the library's defaults; a test session may override entries (tests/conftest.py) to soak a path
+    DEFAULT_TUNING = {_ffi.RT_TUNE_COHERENT_SCALE: 1.0, _ffi.RT_TUNE_SHADOW_LIST: -1, _ffi.RT_TUNE_DARK_KERNEL: -1,
+                      _ffi.RT_TUNE_FILL_MEMSET: 0, _ffi.RT_TUNE_BVH_DEPTH_LIMIT: 28, _ffi.RT_TUNE_HEAVY_CLASS: -1}
+
     def reset_tuning(self):
-        for key, value in ((_ffi.RT_TUNE_COHERENT_SCALE, 1.0), (_ffi.RT_TUNE_SHADOW_LIST, -1), (_ffi.RT_TUNE_DARK_KERNEL, -1),
-                           (_ffi.RT_TUNE_FILL_MEMSET, 0), (_ffi.RT_TUNE_BVH_DEPTH_LIMIT, 28)):
+        for key, value in self.DEFAULT_TUNING.items():
             self.set_tuning(key, value)
 
     def selftest_division(self, n_cases, seed=1):
@@ -260,6 +263,12 @@ class Context:
         a, b = C.c_uint32(), C.c_uint32()
         self._check(self._lib.rt_frame_row_extent(self._ctx, C.byref(frame), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def debug_status(self) -> int:
+        """rt_debug_status: 0 unless a heavy tile's workgroup gave up waiting (never expected)."""
+        w = C.c_uint32()
+        self._check(self._lib.rt_debug_status(self._ctx, C.byref(w)))
+        return w.value
 
     def tile_costs(self):
         """rt_debug_tile_costs: cycles per 8x8 tile of the last launch (uint32 array, launch tile grid order)."""

@@ -23,6 +23,14 @@
 
 using namespace rtx950;
 
+// Heavy tiles, automatic mode: tiles of >= 128 K cycles (one-wave terms) go to render_heavy_kernel on the second
+// stream when the call is the synchronous rt_render (one frame at a time by construction: the frame's slowest
+// tile is its duration) and the launch is small enough to be bound by that tile rather than by throughput.
+// The side stream costs about 12 us per frame in event traffic, and a process that keeps several contexts'
+// frames in flight has more streams than hardware queues (a waiting side kernel then blocks another context's
+// launches): asynchronous callers opt in with RT_TUNE_HEAVY_CLASS.
+constexpr uint32_t kDefaultHeavyClass = 5;
+constexpr size_t kAutoHeavyMaxTiles = 65536;  // 1080p: 32 400 tiles, 4K: 129 600
 constexpr uint32_t kDefaultGrid = 32768;  // swept at the end of round 1, one frame at a time: 24576 +2 %, 28672..49152 within 0.5 %, 65536 +1.5 %
 
 // Work buffers of a launch (device memory beyond inputs and outputs): the tile stamps classify_tiles
@@ -38,6 +46,15 @@ struct TileScratch {
     uint32_t frame_id = 0;    // stamps equal to the launch's frame id are this launch's (ids only grow)
     uint32_t launch_seq = 0;  // selects the queue header bank
     bool growable = true;     // false: fixed capacity, a frame that does not fit is refused (RT_ERR_LIMIT)
+    // heavy tiles (growable sets only): two banks of kHeavyCap list entries, a mark word per tile, and which
+    // launch (sequence number, tile grid) the list that the last launch's build_queue wrote is for
+    uint32_t* heavy = nullptr;
+    size_t heavy_cap = 0;     // in words
+    uint32_t* heavy_mark = nullptr;
+    size_t mark_cap = 0;      // in words
+    bool heavy_list_ready = false;
+    uint32_t heavy_list_seq = 0;
+    uint32_t heavy_geom[6] = {0, 0, 0, 0, 0, 0};  // width, height, y0, y1, n_parts, part
 };
 
 // ---- the allocation-free entry point's work buffers (rt_render_device_noalloc) -------------------------
@@ -61,6 +78,10 @@ static DeviceScratch g_dev_scratch[kMaxDevices];
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // render_heavy_kernel runs here, between an event recorded on `stream` when the call begins and one that
+    // `stream` waits for after its own launches: callers see one stream, as before
+    hipStream_t stream_heavy = nullptr;
+    hipEvent_t heavy_fork = nullptr, heavy_join = nullptr;
     std::string err;
     // scene
     bool has_scene = false;
@@ -102,6 +123,7 @@ struct rt_ctx {
     int tune_shadow_list = -1, tune_dark_kernel = -1;
     bool tune_fill_memset = false;
     uint32_t tune_bvh_depth_limit = kBvhStackMax;
+    int tune_heavy_class = -1;  // -1: automatic (see render_part), 0..7: threshold class, 8: never
     uint32_t max_workgroups = kDefaultGrid;  // grid of render_kernel: 8x the resident single-wave workgroups of an MI355X
     // timing
     bool timing = false;
@@ -257,6 +279,11 @@ void fill_frame(const rt_ctx* ctx, const rt_frame* f, Params& p)
     p.y1 = f->y1;
     p.n_parts = 1u;
     p.part = 0u;
+    p.heavy = nullptr;
+    p.heavy_mark = nullptr;
+    p.heavy_now = 0u;
+    p.heavy_next = 0u;
+    p.heavy_class = kCostClasses;
     {
         float ob = std::max(p.bound_max, p.sphere_bound_max);
         for (int k = 0; k < 3; ++k) ob = std::max(ob, std::fabs(p.eye[k]));
@@ -358,6 +385,12 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts)
     const size_t stamps_before = ts.stamps_cap;
     if ((rc = grow(ctx, ts, &ts.stamps, &ts.stamps_cap, swords, "tile stamps")) != RT_OK) return rc;
     if (ts.stamps_cap != stamps_before) ts.frame_id = 0u;
+    if (ts.growable) {
+        const size_t heavy_before = ts.heavy_cap, mark_before = ts.mark_cap;
+        if ((rc = grow(ctx, ts, &ts.heavy, &ts.heavy_cap, 2 * (size_t)kHeavyCap, "heavy list entries")) != RT_OK) return rc;
+        if ((rc = grow(ctx, ts, &ts.heavy_mark, &ts.mark_cap, n_tiles + 1, "heavy marks")) != RT_OK) return rc;
+        if (ts.heavy_cap != heavy_before || ts.mark_cap != mark_before) ts.heavy_list_ready = false;
+    }
     p.queue = ts.queue;
     // Header banks alternate: this launch counts into bank qsel, which the previous launch (or the fresh
     // buffer) left zeroed, and zeroes the other one for the next launch.
@@ -450,11 +483,22 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
         delete c;
         return fail_hip(nullptr, e, "hipStreamCreateWithFlags");
     }
-    e = hipMalloc((void**)&c->d_counters, kCounterBytes);
+    {
+        // the side stream gets the highest priority there is: its few workgroups are the frame's critical path
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        e = hipStreamCreateWithPriority(&c->stream_heavy, hipStreamNonBlocking, prio_greatest);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->heavy_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->heavy_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, kCounterBytes);
     if (e != hipSuccess) {
+        if (c->heavy_join) (void)hipEventDestroy(c->heavy_join);
+        if (c->heavy_fork) (void)hipEventDestroy(c->heavy_fork);
+        if (c->stream_heavy) (void)hipStreamDestroy(c->stream_heavy);
         (void)hipStreamDestroy(c->stream);
         delete c;
-        return fail_hip(nullptr, e, "hipMalloc(counters)");
+        return fail_hip(nullptr, e, "rt_ctx_create: second stream, events or counter buffer");
     }
     // The fixed work buffer of rt_render_device_noalloc: this device's copy of `scratch`, looked up once per
     // device with the device current (in host code the array's name is not a device address).
@@ -466,6 +510,9 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
             e = hipGetSymbolAddress((void**)&base, HIP_SYMBOL(scratch));
             if (e != hipSuccess || !base) {
                 (void)hipFree(c->d_counters);
+                (void)hipEventDestroy(c->heavy_join);
+                (void)hipEventDestroy(c->heavy_fork);
+                (void)hipStreamDestroy(c->stream_heavy);
                 (void)hipStreamDestroy(c->stream);
                 delete c;
                 return fail_hip(nullptr, e, "hipGetSymbolAddress(scratch)");
@@ -489,6 +536,7 @@ int rt_ctx_destroy(rt_ctx* ctx)
     if (!ctx) return RT_OK;
     DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream_heavy);
     free_scene(ctx);
     (void)hipFree(ctx->d_fb);
     for (auto& b : ctx->d_dbg) (void)hipFree(b);
@@ -496,10 +544,15 @@ int rt_ctx_destroy(rt_ctx* ctx)
     (void)hipFree(ctx->own.stamps);
     (void)hipFree(ctx->own.queue);
     (void)hipFree(ctx->own.cost);
+    (void)hipFree(ctx->own.heavy);
+    (void)hipFree(ctx->own.heavy_mark);
     (void)hipFree(ctx->d_part);
     if (ctx->part_done) (void)hipEventDestroy(ctx->part_done);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    (void)hipEventDestroy(ctx->heavy_join);
+    (void)hipEventDestroy(ctx->heavy_fork);
+    (void)hipStreamDestroy(ctx->stream_heavy);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -791,6 +844,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.bvh = ctx->d_bvh;
     b.n_bvh_nodes = (uint32_t)nodes.size();
     b.coherent_thr = half_n ? (float)(8.0 * half_sum / (double)half_n) : 0.0f;  // 8 average half sizes (swept with the ordered walk: 4..16 within 10 %)
+    b.split_thr = half_n ? (float)(0.5 * half_sum / (double)half_n) : 0.0f;  // heavy tiles: half an average half size of inflation per cube
     if (bvh_depth > ctx->tune_bvh_depth_limit) b.coherent_thr = INFINITY;  // a list too long for the walk's per-lane stack: every wave takes the chunk traversal
     if (std::isfinite(b.coherent_thr)) b.coherent_thr *= ctx->tune_coherent_scale;  // rt_set_tuning: 1 unless a test forces one traversal
     b.spheres = ctx->d_spheres;
@@ -829,13 +883,22 @@ uint32_t rt_part_rows(uint32_t rows, uint32_t n_parts, uint32_t part)
     return total;
 }
 
+static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, uint32_t* d_out_0rgb,
+                       const rt_debug_planes* dbg_device, bool synchronous);
+
 int rt_render_device(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out_0rgb, const rt_debug_planes* dbg_device)
 {
-    return rt_render_device_part(ctx, frame, 1u, 0u, d_out_0rgb, dbg_device);
+    return render_part(ctx, frame, 1u, 0u, d_out_0rgb, dbg_device, false);
 }
 
 int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, uint32_t* d_out_0rgb,
                           const rt_debug_planes* dbg_device)
+{
+    return render_part(ctx, frame, n_parts, part, d_out_0rgb, dbg_device, false);
+}
+
+static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uint32_t part, uint32_t* d_out_0rgb,
+                       const rt_debug_planes* dbg_device, bool synchronous)
 {
     int rc = check_frame(ctx, frame);
     if (rc != RT_OK) return rc;
@@ -850,13 +913,49 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
 #ifdef RTX_PROFILE
     p.counters = ctx->d_counters;
 #endif
-    if ((rc = prepare(ctx, p, ctx->own)) != RT_OK) return rc;
     int variant = kVariantRender;
     if (dbg_device && (dbg_device->hit_cube || dbg_device->hit_sphere || dbg_device->tree_hash)) {
         p.hit_cube = dbg_device->hit_cube;
         p.hit_sphere = dbg_device->hit_sphere;
         p.tree_hash = dbg_device->tree_hash;
         variant = kVariantDebug;
+    }
+    // Heavy tiles: a plain frame whose untraced tiles build_queue paints (no fill that could overwrite the
+    // side kernel's pixels) hands the tiles on the list that the previous launch wrote - same tile grid, next
+    // sequence number - to render_heavy_kernel on the second stream, and writes the list for the next launch.
+    TileScratch& ts = ctx->own;
+    const bool paints = ((uintptr_t)d_out_0rgb & 15u) == 0u && (frame->width & 3u) == 0u && !ctx->tune_fill_memset;
+    const size_t launch_tiles = (size_t)((frame->width + 7u) / 8u) * ((rt_part_rows(frame->y1 - frame->y0, n_parts, part) + 7u) / 8u);
+    const uint32_t heavy_class = ctx->tune_heavy_class >= 0 ? (uint32_t)ctx->tune_heavy_class
+                                 : ((synchronous && launch_tiles <= kAutoHeavyMaxTiles) ? kDefaultHeavyClass : kCostClasses);
+    const bool heavy_on = variant == kVariantRender && paints && heavy_class < kCostClasses;
+    const uint32_t seq = ts.launch_seq;  // this launch's; prepare() increments it
+    const uint32_t geom[6] = {frame->width, frame->height, frame->y0, frame->y1, n_parts, part};
+    bool heavy_fork = false;
+    bool heavy_now = heavy_on && ts.heavy_list_ready && ts.heavy_list_seq == seq && std::memcmp(ts.heavy_geom, geom, sizeof(geom)) == 0 &&
+                     seq + 1u != 0u;
+    if (heavy_now) {
+        // everything enqueued on the context's stream so far (the caller's use of the output buffer included)
+        // comes before the side kernel; this launch's own kernels do not.  An idle stream needs no event.
+        heavy_fork = hipStreamQuery(ctx->stream) != hipSuccess;
+        (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error
+        if (heavy_fork) HIP_TRY(ctx, hipEventRecord(ctx->heavy_fork, ctx->stream));
+    }
+    if ((rc = prepare(ctx, p, ts)) != RT_OK) return rc;
+    heavy_now = heavy_now && ts.heavy_list_ready;  // a buffer that had to grow took the list with it
+    ts.heavy_list_ready = false;
+    if (heavy_on) {
+        p.heavy = ts.heavy;
+        p.heavy_mark = ts.heavy_mark;
+        p.heavy_class = heavy_class;
+        p.split_thr = ctx->base.split_thr;
+        p.heavy_now = heavy_now ? seq + 1u : 0u;
+        p.heavy_next = (seq + 2u != 0u) ? seq + 2u : 0u;
+        if (p.heavy_next != 0u) {
+            ts.heavy_list_ready = true;
+            ts.heavy_list_seq = seq + 1u;
+            std::memcpy(ts.heavy_geom, geom, sizeof(geom));
+        }
     }
     if (variant == kVariantRender) {
         // Three quarters of a typical frame are sky.  Those tiles are painted by build_queue, which has just
@@ -872,7 +971,16 @@ int rt_render_device_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, 
             p.prefilled = 1u;
         }
     }
-    return launch_timed(ctx, p, variant);
+    if ((rc = launch_timed(ctx, p, variant)) != RT_OK) return rc;
+    if (heavy_now) {
+        // after the stream's own launches, so that the host's time for these four calls is not ahead of them
+        if (heavy_fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_heavy, ctx->heavy_fork, 0));
+        hipError_t e = (hipError_t)launch_heavy(p, (void*)ctx->stream_heavy);
+        if (e != hipSuccess) return fail_hip(ctx, e, "heavy kernel launch");
+        HIP_TRY(ctx, hipEventRecord(ctx->heavy_join, ctx->stream_heavy));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->heavy_join, 0));  // the frame is whole when the stream gets here
+    }
+    return RT_OK;
 }
 
 int rt_render(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_0rgb, const rt_debug_planes* dbg_host)
@@ -897,7 +1005,7 @@ int rt_render(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_0rgb, const rt_d
         dev.hit_sphere = host_planes[1] ? ctx->d_dbg[1] : nullptr;
         dev.tree_hash = host_planes[2] ? ctx->d_dbg[2] : nullptr;
     }
-    if ((rc = rt_render_device(ctx, frame, ctx->d_fb, &dev)) != RT_OK) return rc;
+    if ((rc = render_part(ctx, frame, 1u, 0u, ctx->d_fb, &dev, true)) != RT_OK) return rc;
     // the single read-back
     HIP_TRY(ctx, hipMemcpyAsync(out_0rgb, ctx->d_fb, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     for (int k = 0; k < 3; ++k)
@@ -1142,6 +1250,11 @@ int rt_set_tuning(rt_ctx* ctx, int key, double value)
         if (!(value == 0.0 || value == 1.0)) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_FILL_MEMSET must be 0 or 1");
         ctx->tune_fill_memset = value != 0.0;
         return RT_OK;
+    case RT_TUNE_HEAVY_CLASS:
+        if (!(value >= -1.0 && value <= (double)kCostClasses && value == (double)(int)value))
+            return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_HEAVY_CLASS must be -1 (automatic) or an integer in 0..8");
+        ctx->tune_heavy_class = (int)value;
+        return RT_OK;
     case RT_TUNE_BVH_DEPTH_LIMIT:
         if (!(value >= 1.0 && value <= (double)kBvhStackMax && value == (double)(uint32_t)value))
             return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_BVH_DEPTH_LIMIT must be an integer in 1..28");
@@ -1304,6 +1417,16 @@ int rt_render_multi(rt_ctx* const* ctxs, uint32_t n_ctx, const rt_frame* frame, 
     }
     // GPU0's fills above run on its stream; the parts' copies run on theirs and touch other rows
     return rt_gather_bands(ctxs, n_ctx, parts.data(), w, s1 - s0, d_frame_on_ctx0 + (size_t)(s0 - frame->y0) * w, out_bytes_moved);
+}
+
+int rt_debug_status(rt_ctx* ctx, uint32_t* out_word)
+{
+    if (!ctx || !out_word) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
+    *out_word = 0u;
+    ENTER_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own.queue) HIP_TRY(ctx, hipMemcpy(out_word, ctx->own.queue + kQueueBase - 1u, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 int rt_debug_tile_costs(rt_ctx* ctx, uint32_t* out, size_t cap, size_t* out_tiles)

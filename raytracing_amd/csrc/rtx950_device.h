@@ -146,7 +146,28 @@ struct Params {
     // number the host could bound): launch_render picks the kernel that tests for it per lane.  Host-side
     // only, the kernels do not read it.
     uint32_t dark_materials;
+    // ---- heavy tiles (render_heavy_kernel; the members below are read by it and by build_queue only, and sit
+    // behind everything render_kernel reads so that its code stays the same to the instruction)
+    // The tiles whose cost class in this context's earlier launches was >= heavy_class are traced by
+    // render_heavy_kernel on a second stream, concurrently with this launch's classification, listing and
+    // render_kernel: a workgroup of three waves per tile instead of one wave.  The list a launch uses was
+    // written by the PREVIOUS launch's build_queue (the side kernel must not wait for this launch's): entries
+    // heavy[heavy_bank * kHeavyCap + i], i < min(queue[qsel * 16 + kHeavyCountWord], kHeavyCap), a tile column |
+    // tile row << 16 each, and heavy_mark[tile] == heavy_now for exactly those tiles, which build_queue then
+    // neither lists nor paints.  build_queue also writes the next launch's list (bank heavy_bank ^ 1, marks
+    // heavy_next, count in the other header bank).  0 in heavy_now / heavy_next: no list in use / none wanted.
+    uint32_t* heavy;
+    uint32_t* heavy_mark;
+    uint32_t heavy_now, heavy_next;
+    uint32_t heavy_class;
+    float split_thr;  // heavy tiles: a wave whose cull inflation exceeds this is walked bundle by bundle (cube_query, SPLIT)
 };
+constexpr uint32_t kHeavyCap = 1024;       // heavy tiles per launch; the rest stay with render_kernel
+constexpr uint32_t kHeavyTarget = 512;     // classify_tiles raises the class threshold until about this many tiles qualify:
+                                           // what the side kernel's three-wave workgroups can hold at once beside render_kernel
+constexpr uint32_t kHeavyCountWord = 9;    // word of a queue header bank that counts the heavy list's entries
+constexpr uint32_t kHeavyClassWord = 62;   // queue header word: the lowest class that fits (classify_tiles -> build_queue)
+constexpr uint32_t kHeavyGrid = 640;       // workgroups of render_heavy_kernel (striding over the list)
 
 // classify_tiles: one wave per cube projects the cube's padded corners through the frame's camera and
 // stamps the 8x8 pixel tiles its bounding rectangle touches.  Primary rays of unstamped tiles cannot
@@ -176,6 +197,8 @@ enum KernelVariant { kVariantRender = 0, kVariantDebug = 1, kVariantCount = 2 };
 // at most max_workgroups single-wave workgroups striding over the queue.  Both return a hipError_t.
 int launch_queue(const Params& p, int variant, void* stream);
 int launch_render(const Params& p, int variant, void* stream, uint32_t max_workgroups);
+// launch_heavy: render_heavy_kernel for the launch's heavy list (plain frames only), on `stream`
+int launch_heavy(const Params& p, void* stream);
 int launch_classify(const TileParams& t, void* stream);
 // selftest_division: blocks x 256 threads x iters operand pairs; d_out[0] += mismatches, d_out[1] += cases
 int launch_selftest_division(uint32_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out, void* stream);

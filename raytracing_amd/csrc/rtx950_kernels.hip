@@ -696,6 +696,79 @@ DEV bool cull_test(f32x4 k, const CullPre& c)
     return c.all || !sep;  // NaN compares false -> candidate
 }
 
+// ---- the general form of the wave-level cull (render_heavy_kernel only)
+// cull_pre bounds the wave's directions and moments by one radius each around one lane's values, which
+// is as tight as it needs to be for a coherent bundle and costs one DPP sweep.  The heavy tiles' bundles are
+// not coherent: shadow rays towards a light that floats a quarter of a cube in front of the surface fan out
+// over half a radian within one tile, and with a corner lane as the centre and one radius for all axes the
+// bound keeps 80 of the diorama's 97 cubes where the 64 lines meet 10.  This form takes the BOX of the
+// lanes' values - per component, centre and half width from the minimum and the maximum (six sweeps) - and
+// the moments about the reference lane's origin instead of the world's (W' = (o - c) x d, small when the
+// origins are close together whatever the directions do; the cube centres move by -c with them):
+//   |k'_i dc_j - k'_j dc_i - wc_ij|  >  h (a_i + a_j) + |k'_i| rd_j + |k'_j| rd_i + rw_ij   =>  every lane's line misses
+// (the same coordinate-plane tests with d = dc + e, |e_i| <= rd_i, W' = wc + f, |f_ij| <= rw_ij, a_i = |dc_i| +
+// rd_i).  Rounding: the half widths come out of wave_max2 rounded up; recentring adds errors of u (B + O) to
+// the cube centres and the origins, which the slack of cull_pre covers many times over, as it does the
+// rounding of the box centres.
+struct CullPreG {  // wave-uniform
+    float dxc, dyc, dzc;        // centre of the box of directions
+    float wxyc, wyzc, wzxc;     // centre of the box of moments about (cx, cy, cz)
+    float rdx, rdy, rdz;        // half widths of the direction box
+    float rwxy, rwyz, rwzx;     // half widths of the moment box, plus rounding slack
+    float ax, ay, az;           // upper bounds of |d_i|
+    float cx, cy, cz;           // the reference lane's origin: cube centres and moments are taken about it
+    float dr, wr_raw;           // largest half widths (traversal choice of long lists, SPLIT trigger)
+    float omax;
+    bool all;                   // some active ray is non-finite or huge: keep every cube
+};
+// centre and half width of the active lanes' values of v, as offsets from a reference value
+DEV void wave_box(bool active, float v, float ref, float& centre, float& half)
+{
+    const float dlt = v - ref;
+    float up, dn;
+    wave_max2((active && dlt > 0.0f) ? dlt : 0.0f, (active && dlt < 0.0f) ? -dlt : 0.0f, up, dn);
+    centre = ref + 0.5f * (up - dn);
+    half = 0.5f * (up + dn);
+}
+DEV CullPreG cull_pre_g(bool active, V3 o, V3 d, bool wild, float bound_max, float origin_bound)
+{
+    CullPreG c;
+    const unsigned long long am = wave_ballot(active);
+    const unsigned long long am_mid = am >> 20;
+    const uint32_t ref = ((am >> 27) & 1ull) ? 27u : (((am >> 36) & 1ull) ? 36u : (am_mid ? 20u + (uint32_t)__builtin_ctzll(am_mid) : (am ? (uint32_t)__builtin_ctzll(am) : 0u)));
+    c.all = wave_any(active && wild);
+    c.cx = readlane_f(o.x, ref); c.cy = readlane_f(o.y, ref); c.cz = readlane_f(o.z, ref);
+    const float ox = o.x - c.cx, oy = o.y - c.cy, oz = o.z - c.cz;
+    const float wxy = __builtin_fmaf(ox, d.y, -(oy * d.x)), wyz = __builtin_fmaf(oy, d.z, -(oz * d.y)), wzx = __builtin_fmaf(oz, d.x, -(ox * d.z));
+    wave_box(active, d.x, readlane_f(d.x, ref), c.dxc, c.rdx);
+    wave_box(active, d.y, readlane_f(d.y, ref), c.dyc, c.rdy);
+    wave_box(active, d.z, readlane_f(d.z, ref), c.dzc, c.rdz);
+    float rxy, ryz, rzx;
+    wave_box(active, wxy, 0.0f, c.wxyc, rxy);  // the reference lane's own moment about its origin is 0
+    wave_box(active, wyz, 0.0f, c.wyzc, ryz);
+    wave_box(active, wzx, 0.0f, c.wzxc, rzx);
+    c.ax = __builtin_fabsf(c.dxc) + c.rdx; c.ay = __builtin_fabsf(c.dyc) + c.rdy; c.az = __builtin_fabsf(c.dzc) + c.rdz;
+    const float slack = 0x1p-17f * (bound_max + origin_bound + 1.0f) * __builtin_fmaxf(c.ax + c.ay + c.az, 1.0f);  // see cull_pre
+    c.rwxy = rxy + slack; c.rwyz = ryz + slack; c.rwzx = rzx + slack;
+    c.dr = __builtin_fmaxf(c.rdx, __builtin_fmaxf(c.rdy, c.rdz));
+    c.wr_raw = __builtin_fmaxf(rxy, __builtin_fmaxf(ryz, rzx));
+    c.omax = origin_bound;
+    return c;
+}
+DEV bool cull_test(f32x4 k, const CullPreG& c)
+{
+    const float kx = k[0] - c.cx, ky = k[1] - c.cy, kz = k[2] - c.cz;
+    const float akx = __builtin_fabsf(kx), aky = __builtin_fabsf(ky), akz = __builtin_fabsf(kz);
+    const float gxy = __builtin_fmaf(kx, c.dyc, __builtin_fmaf(-ky, c.dxc, -c.wxyc));
+    const float lxy = __builtin_fmaf(k[3], c.ax + c.ay, __builtin_fmaf(akx, c.rdy, __builtin_fmaf(aky, c.rdx, c.rwxy)));
+    const float gyz = __builtin_fmaf(ky, c.dzc, __builtin_fmaf(-kz, c.dyc, -c.wyzc));
+    const float lyz = __builtin_fmaf(k[3], c.ay + c.az, __builtin_fmaf(aky, c.rdz, __builtin_fmaf(akz, c.rdy, c.rwyz)));
+    const float gzx = __builtin_fmaf(kz, c.dxc, __builtin_fmaf(-kx, c.dzc, -c.wzxc));
+    const float lzx = __builtin_fmaf(k[3], c.az + c.ax, __builtin_fmaf(akz, c.rdx, __builtin_fmaf(akx, c.rdz, c.rwzx)));
+    const bool sep = (__builtin_fabsf(gxy) > lxy) || (__builtin_fabsf(gyz) > lyz) || (__builtin_fabsf(gzx) > lzx);
+    return c.all || !sep;  // NaN compares false -> candidate
+}
+
 // ---------------------------------------------------------------- cube queries
 enum { Q_NEAREST = 0, Q_NEAREST_EXACT = 1, Q_SHADOW = 2 };
 
@@ -781,8 +854,8 @@ DEV void cube_candidate(const Params& P, const RayPre& q, bool active, bool any_
 }
 
 // One pass over a short cube list (at most kSmallChunks chunks of 64, in list order) for the whole wave.
-template <int MODE>
-DEV void cube_query_small(const Params& P, const RayPre& q, const CullPre& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
+template <int MODE, typename CP>
+DEV void cube_query_small(const Params& P, const RayPre& q, const CP& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
     const uint32_t n = P.n_cubes;
     const bool any_zero = wave_any(active && q.zbits != 0u);
@@ -836,6 +909,20 @@ DEV bool chunk_test(f32x4 k, f32x4 h, const CullPre& c)
     return c.all || !sep;
 }
 
+DEV bool chunk_test(f32x4 k, f32x4 h, const CullPreG& c)
+{
+    const float kx = k[0] - c.cx, ky = k[1] - c.cy, kz = k[2] - c.cz;
+    const float akx = __builtin_fabsf(kx), aky = __builtin_fabsf(ky), akz = __builtin_fabsf(kz);
+    const float gxy = __builtin_fmaf(kx, c.dyc, __builtin_fmaf(-ky, c.dxc, -c.wxyc));
+    const float lxy = __builtin_fmaf(h[0], c.ay, __builtin_fmaf(h[1], c.ax, __builtin_fmaf(akx, c.rdy, __builtin_fmaf(aky, c.rdx, c.rwxy))));
+    const float gyz = __builtin_fmaf(ky, c.dzc, __builtin_fmaf(-kz, c.dyc, -c.wyzc));
+    const float lyz = __builtin_fmaf(h[1], c.az, __builtin_fmaf(h[2], c.ay, __builtin_fmaf(aky, c.rdz, __builtin_fmaf(akz, c.rdy, c.rwyz))));
+    const float gzx = __builtin_fmaf(kz, c.dxc, __builtin_fmaf(-kx, c.dzc, -c.wzxc));
+    const float lzx = __builtin_fmaf(h[2], c.ax, __builtin_fmaf(h[0], c.az, __builtin_fmaf(akz, c.rdx, __builtin_fmaf(akx, c.rdz, c.rwzx))));
+    const bool sep = (__builtin_fabsf(gxy) > lxy) || (__builtin_fabsf(gyz) > lyz) || (__builtin_fabsf(gzx) > lzx);
+    return c.all || !sep;
+}
+
 // One pass over a long cube list.  The cull stream of such a scene is in Morton order of the cube centres
 // (rt_scene_upload), so a chunk of 64 consecutive records is spatially compact and has a tight bounding
 // box: lane j first tests chunk j's box against the wave's rays (same separating-axis test, three half
@@ -843,8 +930,8 @@ DEV bool chunk_test(f32x4 k, f32x4 h, const CullPre& c)
 // stream order, not list order; cube_perm gives each its list index, and cube_candidate's folds do not
 // depend on the visiting order.  (The reference walks all N cubes per ray; 10k cubes = 157 chunks, of
 // which a coherent bundle meets a handful.)
-template <int MODE>
-DEV void cube_query_large(const Params& P, const RayPre& q, const CullPre& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
+template <int MODE, typename CP>
+DEV void cube_query_large(const Params& P, const RayPre& q, const CP& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
     const uint32_t n = P.n_cubes, n_chunks = P.n_chunks;
     const bool any_zero = wave_any(active && q.zbits != 0u);
@@ -938,10 +1025,12 @@ DEV void cube_query_large(const Params& P, const RayPre& q, const CullPre& cp, b
 // (every cube in a box has distance >= the box's entry parameter, negative ones included; E = tol/2 as
 // for cubes, the box lies within the scene bounds), subtrees whose lowest list index is not below the
 // blocker.  Unsafe rays have tol = inf and NaN compares false: they visit everything.
+constexpr uint32_t kWgWaves = 3;  // waves of a render_heavy_kernel workgroup (one tracer, two shaders for a heavy tile)
+template <uint32_t WAVES>
 DEV uint32_t* bvh_stack()
 {
-    __shared__ uint32_t s[kBvhStackMax * 64u];  // [level][lane]; only kernels of long lists carry it
-    return s;
+    __shared__ uint32_t s[WAVES][kBvhStackMax * 64u];  // [wave][level][lane]; only kernels of long lists carry it
+    return s[(threadIdx.x >> 6) % WAVES];
 }
 
 struct BoxTest { float lo; bool hit; };
@@ -965,7 +1054,7 @@ DEV bool box_zero_axis_miss(const RayPre& q, V3 o, f32x4 c, f32x4 h)
            (zz && __builtin_fabsf(c[2] - o.z) > h[2] + q.zdelta);
 }
 
-template <int MODE>
+template <int MODE, uint32_t WAVES>
 DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
     const bool any_zero = wave_any(active && q.zbits != 0u);
@@ -975,7 +1064,7 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
     PROF_MARK(PH_PRE);
     const uint32_t lane = threadIdx.x & 63u;
     const f32x4* nodes = (const f32x4*)P.bvh;
-    uint32_t* stack = bvh_stack() + lane;
+    uint32_t* stack = bvh_stack<WAVES>() + lane;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     uint32_t pair = active ? 0u : kNone;  // pair 0: the children of the root
     uint32_t sp = 0u;
@@ -1034,21 +1123,56 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
 
 // LARGE (a kernel template parameter chosen by the length of the cube list) keeps the long-list code out
 // of the kernel that renders short lists: compiled in, it cost the 97-cube benchmark scene 6 %.
-template <int MODE, bool LARGE>
-DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
+template <int MODE, bool LARGE, uint32_t WAVES, typename CP>
+DEV void cube_query_run(const Params& P, const RayPre& q, const CP& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
+{
+    if constexpr (LARGE) {
+        // how much the wave's spread inflates every cube in cull_test, against the cubes' own size (wave-uniform)
+        const bool coherent = cp.all || !(__builtin_fmaf(2.0f * P.bound_max, cp.dr, cp.wr_raw) > P.coherent_thr);
+        if (coherent) cube_query_large<MODE, CP>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+        else cube_query_bvh<MODE, WAVES>(P, q, active, o, d, impact_id, st PROF_PASS);
+    } else {
+        cube_query_small<MODE, CP>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+    }
+}
+
+// SPLIT (heavy tiles only, render_heavy_kernel's tracer and shaders): a wave whose rays come in several
+// bundles - an 8x8 tile across the edge between two faces sends its secondary rays two ways, and the
+// reference's negative-distance rule can put the hit points of one bundle on the far side of the scene -
+// has a wave-level bound that keeps every cube.  `key` names a lane's bundle (the faces its ray tree has
+// come through, see trace_tree); when the wave's bound is loose and the keys differ, the lanes are walked
+// key by key, each bundle with its own bound (at most kMaxBundles passes, the last takes all the rest).
+// The folds are per lane, so the order and grouping of the passes change no result.
+constexpr uint32_t kMaxBundles = 3u;
+template <int MODE, bool LARGE, bool SPLIT = false>
+DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st, uint32_t key PROF_ARG)
 {
     if (P.n_cubes == 0u) return;
     const RayPre q = ray_pre(P, o, d);
     st.tol = q.tol;
     st.div_ok = q.div_ok;
-    const CullPre cp = cull_pre(active, o, d, q.wild, P.bound_max, P.origin_bound);
-    if constexpr (LARGE) {
-        // how much the wave's spread inflates every cube in cull_test, against the cubes' own size (wave-uniform)
-        const bool coherent = cp.all || !(__builtin_fmaf(2.0f * P.bound_max, cp.dr, cp.wr_raw) > P.coherent_thr);
-        if (coherent) cube_query_large<MODE>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
-        else cube_query_bvh<MODE>(P, q, active, o, d, impact_id, st PROF_PASS);
+    if constexpr (SPLIT) {
+        // heavy tiles: the general cull (cull_pre_g), and bundle by bundle where that is still loose
+        const CullPreG cp = cull_pre_g(active, o, d, q.wild, P.bound_max, P.origin_bound);
+        const unsigned long long am = wave_ballot(active);
+        const uint32_t key0 = (uint32_t)__builtin_amdgcn_readlane((int)key, am ? (int)__builtin_ctzll(am) : 0);
+        if (!cp.all && (__builtin_fmaf(2.0f * P.bound_max, cp.dr, cp.wr_raw) > P.split_thr) && wave_any(active && key != key0)) {
+            bool rem = active;
+            for (uint32_t b = 0; b < kMaxBundles; ++b) {
+                const unsigned long long rm = wave_ballot(rem);
+                if (rm == 0ull) break;
+                const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(rm));
+                const bool sel = rem && ((b + 1u == kMaxBundles) || (key == kb));
+                const CullPreG cpb = cull_pre_g(sel, o, d, q.wild, P.bound_max, P.origin_bound);
+                cube_query_run<MODE, LARGE, kWgWaves, CullPreG>(P, q, cpb, sel, o, d, impact_id, st PROF_PASS);
+                rem = rem && !sel;
+            }
+            return;
+        }
+        cube_query_run<MODE, LARGE, kWgWaves, CullPreG>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
     } else {
-        cube_query_small<MODE>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+        const CullPre cp = cull_pre(active, o, d, q.wild, P.bound_max, P.origin_bound);
+        cube_query_run<MODE, LARGE, 1u, CullPre>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
     }
 }
 
@@ -1110,8 +1234,8 @@ DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_
 
 // ---------------------------------------------------------------- nearest hit (render.rs:87-101)
 // `pass` is wave-uniform: PASS_SPHERES walks the sphere list, PASS_CUBES the cube list.
-template <bool COUNT, bool LARGE>
-DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3 d, bool& div_ok, Counters& cnt PROF_ARG)
+template <bool COUNT, bool LARGE, bool SPLIT = false>
+DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3 d, bool& div_ok, Counters& cnt, uint32_t key PROF_ARG)
 {
     uint32_t best_idx = kNoHit;
     div_ok = false;
@@ -1120,13 +1244,13 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
         st.b1 = __builtin_inff(); st.b2 = __builtin_inff(); st.i1 = kNoHit;
         st.best = __builtin_inff(); st.best_i = kNoHit; st.done = false; st.blocker = kNoHit; st.tol = 0.0f; st.div_ok = false;
         st.ev_cull = 0u; st.ev_chunk = 0u; st.ev_cand = 0u; st.ev_exact = 0u; st.ev_bvh = 0u;
-        cube_query<Q_NEAREST, LARGE>(P, active, o, d, 0u, st PROF_PASS);
+        cube_query<Q_NEAREST, LARGE, SPLIT>(P, active, o, d, 0u, st, key PROF_PASS);
         best_idx = active ? st.i1 : kNoHit;
         div_ok = st.div_ok;
         // contested: a second candidate within 2E of the best (exact duplicates, shared edges).  NaN -> contested.
         const bool contested = active && (st.i1 != kNoHit) && !(st.b2 - st.b1 > st.tol);
         if (wave_any(contested)) {
-            cube_query<Q_NEAREST_EXACT, LARGE>(P, contested, o, d, 0u, st PROF_PASS);
+            cube_query<Q_NEAREST_EXACT, LARGE, SPLIT>(P, contested, o, d, 0u, st, key PROF_PASS);
             PROF_MARK(PH_CONTESTED);
             best_idx = contested ? st.best_i : best_idx;
             if constexpr (COUNT) cnt.ev[EV_QUERY] += contested ? 1u : 0u;
@@ -1155,8 +1279,8 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
 // ---------------------------------------------------------------- shadow (render.rs:44-70)
 // First object in array order, among those whose id differs from the impact object's
 // (render.rs:113), whose ray_intersect returns Some.  Not the nearest one.
-template <bool COUNT, bool LARGE>
-DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V3 light_pos, V3 dir, uint32_t impact_id, uint32_t& blocker, Counters& cnt PROF_ARG)
+template <bool COUNT, bool LARGE, bool SPLIT = false>
+DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V3 light_pos, V3 dir, uint32_t impact_id, uint32_t& blocker, Counters& cnt, uint32_t key PROF_ARG)
 {
     // dir = normalize(light_pos - origin) (render.rs:46), the caller's light_dir: the same expression
     blocker = kNoHit;
@@ -1170,7 +1294,7 @@ DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V
         st.b1 = 0.0f; st.b2 = 0.0f; st.i1 = kNoHit; st.best = 0.0f; st.best_i = kNoHit;
         st.done = false; st.blocker = kNoHit; st.tol = 0.0f; st.div_ok = false;
         st.ev_cull = 0u; st.ev_chunk = 0u; st.ev_cand = 0u; st.ev_exact = 0u; st.ev_bvh = 0u;
-        cube_query<Q_SHADOW, LARGE>(P, active, origin, dir, impact_id, st PROF_PASS);
+        cube_query<Q_SHADOW, LARGE, SPLIT>(P, active, origin, dir, impact_id, st, key PROF_PASS);
         blocker = (active && st.done) ? st.blocker : kNoHit;
         if constexpr (COUNT) {
             cnt.ev[EV_CULL] += st.ev_cull; cnt.ev[EV_CHUNK] += st.ev_chunk; cnt.ev[EV_CAND] += st.ev_cand;
@@ -1239,8 +1363,9 @@ enum { F_RO = 0, F_RD = 3, F_SUMF = 6, F_C0 = 7, F_KR = 8, F_KT = 9, F_H = 10, F
 constexpr uint32_t kEntryNoCubes = 1u << 15;  // queue entry flag: the tile's cube pass is answered without tracing
 constexpr uint32_t kPaintGroup = 16;  // untraced tiles painted per surplus workgroup
 constexpr int kStackDepth = 3;  // nodes at depth 0..2 can wait for traced children (max_depth <= 3)
-template <bool DBG>
-constexpr int frame_words() { return DBG ? 12 : 10; }
+template <bool DBG, bool SPLIT = false>
+constexpr int frame_words() { return DBG ? 12 : (SPLIT ? 11 : 10); }
+constexpr int F_KEY = 10;  // SPLIT (plain variants only): the bundle key of the node's refraction child
 constexpr uint32_t kHitFlag = 1u << 24;  // in F_SUMF, above the packed 0x00RRGGBB light sum
 
 // min(255, sum + L*trunc(c_refl*k_r) + L*trunc(c_refr*k_t)) for lanes with a hit, sky otherwise
@@ -1257,13 +1382,152 @@ DEV uint32_t node_finish(const Params& P, uint32_t sumf, float k_r, float k_t, u
     return (sumf & kHitFlag) ? col_to_hex(lit) : P.sky;
 }
 
+// ---------------------------------------------------------------- heavy tiles: one tile on three waves
+// A tile is one wave, and a wave alone on its SIMD issues an instruction every 4-5 cycles: the tiles across
+// cube edges (incoherent secondary bundles, chains of four nodes with three list traversals each) take as
+// long as the whole rest of the frame.  render_heavy_kernel gives such a tile a workgroup of three waves: the
+// TRACER (wave 0) walks the ray tree - nearest hit, hit resolution, child rays - and posts each node's
+// shading input to a mailbox in LDS instead of running the light fold itself; the SHADERS (waves 1, 2) take
+// the posted nodes, each runs the fold's iterations for its share of the lights (shadow query + Phong terms,
+// light_term below) and returns the packed partial sum.  The tracer is already on the next node of the chain
+// while the shaders work, and collects a node's sum when it finishes the node on the way back up.  The
+// fold's operands are non-negative u8 and `+` saturates, so partial sums combine in any order:
+// min(255, min(255, A) + min(255, B)) = min(255, A + B).  Every pixel is computed by the same functions in
+// the same arithmetic as in the one-wave walk; only the wave that executes them differs.
+//
+// The mailbox has one slot per tree depth: the walk holds at most one unfinished node per depth (a node's
+// second child is traced after its first has returned), so a slot is free again when the tracer has
+// collected its node.  posted[k] / done[k][w] are sequence numbers that only grow (release/acquire at
+// workgroup scope); all waves of a workgroup are resident together, so the polling loops cannot starve.
+constexpr uint32_t kShaders = kWgWaves - 1u;
+constexpr uint32_t kMailDepth = 4u;   // tree depths 0..3 (max_depth <= 3)
+constexpr uint32_t kRecWords = 13u;   // hit point, normal, view direction (3 each), packed texel*albedo.0, material | lit << 31, impact id, bundle key
+struct MailCtl {                      // wave-uniform control words, apart from the record overlay
+    uint32_t posted[kMailDepth];
+    uint32_t done[kMailDepth][kShaders];
+    uint32_t pass_ambient[kMailDepth][2];  // the node's pass and ambient term (uniform)
+    uint32_t items_done;              // heavy items the tracer has finished
+#ifdef RTX_PROFILE
+    uint32_t prof_wait, prof_busy[kShaders], prof_nodes[kShaders], prof_posts;
+#endif
+    uint32_t error;                   // a polling loop gave up (never expected; rt_debug_status reports it)
+};
+struct Mailbox {
+    uint32_t* rec;      // [kMailDepth][kRecWords][64]
+    uint32_t* res;      // [kMailDepth][kShaders][64] packed 0x00RRGGBB partial sums
+    MailCtl* ctl;
+};
+constexpr uint32_t kMailWords = kMailDepth * kRecWords * 64u + kMailDepth * kShaders * 64u;
+constexpr uint32_t kSpinLimit = 1u << 22;  // polls before a waiting wave gives up (seconds; a tile takes microseconds)
+
+DEV uint32_t lds_load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void lds_store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// tracer: hand the node at `depth` to the shaders
+DEV void mail_post(const Mailbox& mb, uint32_t depth, uint32_t pass, float ambient, V3 hit_p, V3 hit_n, V3 view_dir, Col tx_a, uint32_t material, bool lit,
+                   uint32_t hit_id, uint32_t key)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* r = mb.rec + depth * (kRecWords * 64u) + lane;
+    r[0 * 64] = __builtin_bit_cast(uint32_t, hit_p.x); r[1 * 64] = __builtin_bit_cast(uint32_t, hit_p.y); r[2 * 64] = __builtin_bit_cast(uint32_t, hit_p.z);
+    r[3 * 64] = __builtin_bit_cast(uint32_t, hit_n.x); r[4 * 64] = __builtin_bit_cast(uint32_t, hit_n.y); r[5 * 64] = __builtin_bit_cast(uint32_t, hit_n.z);
+    r[6 * 64] = __builtin_bit_cast(uint32_t, view_dir.x); r[7 * 64] = __builtin_bit_cast(uint32_t, view_dir.y); r[8 * 64] = __builtin_bit_cast(uint32_t, view_dir.z);
+    r[9 * 64] = col_to_hex(tx_a);  // exact u8 values per channel
+    r[10 * 64] = (material & 0x7FFFFFFFu) | (lit ? 0x80000000u : 0u);
+    r[11 * 64] = hit_id;
+    r[12 * 64] = key;
+    if (lane == 0u) {
+        mb.ctl->pass_ambient[depth][0] = pass;
+        mb.ctl->pass_ambient[depth][1] = __builtin_bit_cast(uint32_t, ambient);
+    }
+    const uint32_t seq = mb.ctl->posted[depth] + 1u;  // only this wave writes it
+    lds_store_release(&mb.ctl->posted[depth], seq);   // the whole wave stores the same word: the records above are visible first
+}
+
+// tracer: the node's light sum, min(255, sum over the shaders' partial sums), packed
+DEV uint32_t mail_collect(const Mailbox& mb, uint32_t depth)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t want = mb.ctl->posted[depth];
+#ifdef RTX_PROFILE
+    const uint32_t prof_c0 = (uint32_t)__builtin_readcyclecounter();
+#endif
+    for (uint32_t w = 0; w < kShaders; ++w) {
+        uint32_t spins = 0u;
+        while (lds_load_acquire(&mb.ctl->done[depth][w]) != want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) { mb.ctl->error = 1u; break; }
+        }
+    }
+#ifdef RTX_PROFILE
+    if (lane == 0u) mb.ctl->prof_wait += (uint32_t)__builtin_readcyclecounter() - prof_c0;
+#endif
+    Col sum = Col{0.0f, 0.0f, 0.0f};
+    for (uint32_t w = 0; w < kShaders; ++w) sum = col_add(sum, col_from_hex(mb.res[(depth * kShaders + w) * 64u + lane]));
+    return col_to_hex(sum);
+}
+
+// One iteration of the light fold of cast_ray (render.rs:104-152, :221-224 without the children): the term
+// (diffuse + specular) * (1 - reflectivity - transparency) of light `li` for the wave's hit points.  `lit`:
+// lanes that cast the shadow ray (a hit whose direct light is not exactly black, see trace_tree).
+template <bool DBG, bool COUNT, bool LARGE, bool SPLIT = false>
+DEV Col light_term(const Params& P, uint32_t pass, uint32_t li, bool lit, bool hit_any, V3 hit_p, V3 hit_n, uint32_t hit_id, V3 view_dir, Col tx_a,
+                   float m_specular, float m_albedo1, float k_ds, float ambient, uint32_t& h, Counters& cnt, uint32_t key PROF_ARG)
+{
+    const LightRec L = P.lights[li];
+    const V3 lp = v3(L.px, L.py, L.pz);
+    const V3 light_dir = vnormalize(vsub(lp, hit_p));
+    uint32_t blocker;
+    PROF_MARK(PH_SHADE);
+    const float shadow = shadow_query<COUNT, LARGE, SPLIT>(P, pass, lit, hit_p, lp, light_dir, hit_id, blocker, cnt, key PROF_PASS);
+    if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
+    if constexpr (COUNT) cnt.ev[EV_LIGHT] += hit_any ? 1u : 0u;
+    const float light_intensity = L.intensity * (1.0f - shadow);
+    const float diffuse_intensity = rs_clamp(vdot(hit_n, light_dir), 0.0f, 1.0f) + ambient;
+    const Col diffuse = col_mul(col_mul(tx_a, diffuse_intensity), light_intensity);
+    // The specular term is trunc(trunc(trunc(c * albedo.1) * spec) * intensity) per channel with
+    // c <= c_max <= 255 (the light's brightest channel): exactly black when c_max * albedo.1 * spec < 1, the
+    // usual case away from highlights.
+    // That can be seen before the reflection direction is normalised and the power taken:
+    // reflect() of two unit vectors has length 1 (checked: within 1 %), so the cosine is at most
+    // cb = the raw dot product + 0.6 % + 1e-5 (50x the rounding of either route), powf is monotone
+    // in its base, and exp2(y log2 cb) is within 1e-3 of cb^y (see powf_like_libm).  NaNs fail
+    // every compare and take the full route.
+    Col specular = Col{0.0f, 0.0f, 0.0f};
+    const uint32_t lc = L.color_0rgb;  // wave-uniform: the light's brightest channel bounds c
+    const uint32_t lc_rg = ((lc >> 16) & 0xFFu) > ((lc >> 8) & 0xFFu) ? ((lc >> 16) & 0xFFu) : ((lc >> 8) & 0xFFu);
+    const float c_max = (float)(lc_rg > (lc & 0xFFu) ? lc_rg : (lc & 0xFFu));
+    const V3 refl_raw = reflect(vneg(light_dir), hit_n);
+    const float rr = vdot(refl_raw, refl_raw);
+    const float c_raw = vdot(view_dir, refl_raw);
+    const float cb = c_raw + __builtin_fabsf(c_raw) * 0x1.8p-8f + 1e-5f;
+    const float e_b = m_specular * __builtin_amdgcn_logf(cb);  // cb <= 0: NaN or -inf times y > 0
+    const bool dark = (rr > 0.99f) && (rr < 1.01f) && (m_specular > 0.0f) &&
+                      ((cb <= 0.0f) || ((cb < 1.0f) && (__builtin_amdgcn_exp2f(e_b) * (c_max * m_albedo1) < 0.98f)));
+    if (wave_any(lit && !dark)) {
+        const V3 reflect_dir = vnormalize(refl_raw);
+        const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m_specular);
+        if (wave_any(!(spec_i < 0x1p-8f)))
+            specular = col_mul(col_mul(col_mul(col_from_hex(L.color_0rgb), m_albedo1), spec_i), light_intensity);
+    }
+    return col_mul(col_add(diffuse, specular), k_ds);
+}
+
 // One pass of render.rs:298-312 (spheres with ambient 1, or cubes with ambient_light) for the wave's
 // 64 primary rays: returns the packed colour, the primary hit index and the tree hash per lane.
-template <bool DBG, bool COUNT, bool LARGE, bool DARK>
+// ASYNC (render_heavy_kernel's tracer, plain variant only): the light fold of a node is posted to the
+// workgroup's shader waves (`mb`) and its sum collected when the node is finished.
+template <bool DBG, bool COUNT, bool LARGE, bool DARK, bool ASYNC = false, bool SPLIT = ASYNC>
 DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d, float ambient, uint32_t* stk, uint32_t& hash, uint32_t& hit_idx,
-                        Totals& tot PROF_ARG)
+                        Totals& tot, const Mailbox& mb PROF_ARG)
 {
-    constexpr int F = frame_words<DBG>();
+    static_assert(!ASYNC || (!DBG && !COUNT), "the shader waves compute neither blocker hashes nor counters");
+    static_assert(!SPLIT || !DBG, "the debug variant's frame has no room for bundle keys");
+    constexpr int F = frame_words<DBG, SPLIT>();
+    uint32_t postbits = 0u;  // ASYNC, bit k: the node waiting at depth k has a posted light fold (wave-uniform)
+    // SPLIT: the bundle a lane's current ray belongs to (cube_query's SPLIT): the faces and child kinds its
+    // tree has come through, 4 bits a level; primary rays are one bundle
+    uint32_t bkey = 0u;
     const uint32_t lane = threadIdx.x & 63u;
     hit_idx = kNoHit;
     hash = kHashCut;
@@ -1279,8 +1543,9 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
             Counters cnt = {};
             PROF_MARK(PH_OTHER);
             PROF_KIND(depth * 2u);
+            if constexpr (ASYNC) postbits &= ~(1u << depth);
             bool div_ok;
-            const uint32_t idx = nearest_query<COUNT, LARGE>(P, pass, act, o, d, div_ok, cnt PROF_PASS);
+            const uint32_t idx = nearest_query<COUNT, LARGE, SPLIT>(P, pass, act, o, d, div_ok, cnt, bkey PROF_PASS);
             if (depth == 0u) hit_idx = idx;
             uint32_t h = hmix(kHashBasis, idx);
             const bool hit_any = act && (idx != kNoHit);
@@ -1288,6 +1553,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
             float k_r = 0.0f, k_t = 0.0f;
             bool has_refl = false, has_refr = false;
             V3 refl_o = o, refl_d = d, refr_o = o, refr_d = d;
+            uint32_t nkey = 0u;  // SPLIT: this node's bundle key = its ray's key, then the face that was hit
             if (wave_any(hit_any)) {
                 const uint32_t sidx = hit_any ? idx : 0u;  // lanes without a hit shade object 0 and discard the result
                 if constexpr (COUNT) {
@@ -1299,6 +1565,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                 else hit = sphere_resolve(P, sidx, o, d);
                 const MatRec m = P.mats[hit.material];
                 PROF_MARK(PH_RESOLVE);
+                if constexpr (SPLIT) nkey = (bkey * 16u + (uint32_t)hit.face * 2u) & 0x00FFFFFEu;
 
                 Col tx;
                 if (m.texture >= 0) tx = texel_of_face(P, m.texture, hit.face, hit.u * P.sprite, hit.v * P.sprite);
@@ -1319,45 +1586,18 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                     lit = hit_any && !(k_ds < 0.0039f);
                     nl_cast = wave_any(lit) ? nl : 0u;
                 }
-                for (uint32_t li = 0; li < nl_cast; ++li) {
-                    const LightRec L = P.lights[li];
-                    const V3 lp = v3(L.px, L.py, L.pz);
-                    const V3 light_dir = vnormalize(vsub(lp, hit.p));
-                    uint32_t blocker;
-                    PROF_MARK(PH_SHADE);
-                    PROF_KIND(depth * 2u + 1u);
-                    const float shadow = shadow_query<COUNT, LARGE>(P, pass, lit, hit.p, lp, light_dir, hit.id, blocker, cnt PROF_PASS);
-                    if constexpr (DBG) h = hit_any ? hmix(h, blocker) : h;
-                    if constexpr (COUNT) cnt.ev[EV_LIGHT] += hit_any ? 1u : 0u;
-                    const float light_intensity = L.intensity * (1.0f - shadow);
-                    const float diffuse_intensity = rs_clamp(vdot(hit.n, light_dir), 0.0f, 1.0f) + ambient;
-                    const Col diffuse = col_mul(col_mul(tx_a, diffuse_intensity), light_intensity);
-                    // The specular term is trunc(trunc(trunc(c * albedo.1) * spec) * intensity) per channel with
-                    // c <= c_max <= 255 (the light's brightest channel): exactly black when c_max * albedo.1 * spec < 1, the
-                    // usual case away from highlights.
-                    // That can be seen before the reflection direction is normalised and the power taken:
-                    // reflect() of two unit vectors has length 1 (checked: within 1 %), so the cosine is at most
-                    // cb = the raw dot product + 0.6 % + 1e-5 (50x the rounding of either route), powf is monotone
-                    // in its base, and exp2(y log2 cb) is within 1e-3 of cb^y (see powf_like_libm).  NaNs fail
-                    // every compare and take the full route.
-                    Col specular = Col{0.0f, 0.0f, 0.0f};
-                    const uint32_t lc = L.color_0rgb;  // wave-uniform: the light's brightest channel bounds c
-                    const uint32_t lc_rg = ((lc >> 16) & 0xFFu) > ((lc >> 8) & 0xFFu) ? ((lc >> 16) & 0xFFu) : ((lc >> 8) & 0xFFu);
-                    const float c_max = (float)(lc_rg > (lc & 0xFFu) ? lc_rg : (lc & 0xFFu));
-                    const V3 refl_raw = reflect(vneg(light_dir), hit.n);
-                    const float rr = vdot(refl_raw, refl_raw);
-                    const float c_raw = vdot(view_dir, refl_raw);
-                    const float cb = c_raw + __builtin_fabsf(c_raw) * 0x1.8p-8f + 1e-5f;
-                    const float e_b = m.specular * __builtin_amdgcn_logf(cb);  // cb <= 0: NaN or -inf times y > 0
-                    const bool dark = (rr > 0.99f) && (rr < 1.01f) && (m.specular > 0.0f) &&
-                                      ((cb <= 0.0f) || ((cb < 1.0f) && (__builtin_amdgcn_exp2f(e_b) * (c_max * m.albedo1) < 0.98f)));
-                    if (wave_any(lit && !dark)) {
-                        const V3 reflect_dir = vnormalize(refl_raw);
-                        const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m.specular);
-                        if (wave_any(!(spec_i < 0x1p-8f)))
-                            specular = col_mul(col_mul(col_mul(col_from_hex(L.color_0rgb), m.albedo1), spec_i), light_intensity);
+                if constexpr (ASYNC) {
+                    if (nl_cast != 0u) {
+                        mail_post(mb, depth, pass, ambient, hit.p, hit.n, view_dir, tx_a, hit.material, lit, hit.id, nkey);
+                        postbits |= 1u << depth;
                     }
-                    sum = col_add(sum, col_mul(col_add(diffuse, specular), k_ds));
+                } else {
+                    for (uint32_t li = 0; li < nl_cast; ++li) {
+                        PROF_KIND(depth * 2u + 1u);
+                        const Col term = light_term<DBG, COUNT, LARGE, SPLIT>(P, pass, li, lit, hit_any, hit.p, hit.n, hit.id, view_dir, tx_a, m.specular,
+                                                                              m.albedo1, k_ds, ambient, h, cnt, nkey PROF_PASS);
+                        sum = col_add(sum, term);
+                    }
                 }
                 PROF_MARK(PH_SHADE);
                 // children (render.rs:154-193)
@@ -1380,7 +1620,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                 for (uint32_t k = 0; k < depth; ++k) w *= P.n_lights;
                 totals_add(tot, cnt, w);
             }
-            const uint32_t sumf = col_to_hex(sum) | (hit_any ? kHitFlag : 0u);
+            uint32_t sumf = col_to_hex(sum) | (hit_any ? kHitFlag : 0u);  // ASYNC: the light sum is collected when the node is finished
             const bool any_child = has_refl || has_refr;
             if (depth < P.max_depth && wave_any(any_child)) {
                 // wait for the children: the lane's first child is its reflection if it has one, else its
@@ -1393,11 +1633,13 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                 fr[(F_RD + 1) * 64] = __builtin_bit_cast(uint32_t, refr_d.y);
                 fr[(F_RD + 2) * 64] = __builtin_bit_cast(uint32_t, refr_d.z);
                 fr[F_SUMF * 64] = sumf;
+                if constexpr (SPLIT) fr[F_KEY * 64] = nkey;
                 fr[F_KR * 64] = __builtin_bit_cast(uint32_t, k_r);
                 fr[F_KT * 64] = __builtin_bit_cast(uint32_t, k_t);
                 if constexpr (DBG) fr[F_H * 64] = h;
                 o = has_refl ? refl_o : refr_o;
                 d = has_refl ? refl_d : refr_d;
+                if constexpr (SPLIT) bkey = has_refl ? (nkey | 1u) : nkey;
                 act = any_child;
                 slotbits &= ~(1u << depth);
                 depth += 1u;
@@ -1405,6 +1647,9 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
             }
             // children beyond max_depth return the sky colour without tracing (render.rs:80-82)
             const uint32_t zero = 0u;
+            if constexpr (ASYNC) {
+                if ((postbits >> depth) & 1u) sumf |= mail_collect(mb, depth);
+            }
             res = node_finish(P, sumf, k_r, k_t, has_refl ? P.sky : zero, has_refr ? P.sky : zero);
             if constexpr (DBG) res_h = hit_any ? hmix(hmix(h, has_refl ? kHashCut : 0u), has_refr ? kHashCut : 0u) : h;
             unwinding = true;
@@ -1414,7 +1659,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
         depth -= 1u;
         PROF_MARK(PH_OTHER);
         uint32_t* fr = stk + (depth * F) * 64u + lane;
-        const uint32_t sumf = fr[F_SUMF * 64];
+        uint32_t sumf = fr[F_SUMF * 64];
         const float k_r = __builtin_bit_cast(float, fr[F_KR * 64]);
         const float k_t = __builtin_bit_cast(float, fr[F_KT * 64]);
         const bool hit_any = (sumf & kHitFlag) != 0u;
@@ -1432,6 +1677,7 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                 d = v3(__builtin_bit_cast(float, fr[(F_RD + 0) * 64]), __builtin_bit_cast(float, fr[(F_RD + 1) * 64]),
                        __builtin_bit_cast(float, fr[(F_RD + 2) * 64]));
                 act = has_refl && has_refr;
+                if constexpr (SPLIT) bkey = fr[F_KEY * 64];  // the refraction child's bundle
                 slotbits |= 1u << depth;
                 depth += 1u;
                 unwinding = false;
@@ -1448,6 +1694,9 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
         const uint32_t zero = 0u;
         const uint32_t c_refl = has_refl ? c0 : zero;
         const uint32_t c_refr = has_refr ? (has_refl ? c1 : c0) : zero;
+        if constexpr (ASYNC) {
+            if ((postbits >> depth) & 1u) sumf |= mail_collect(mb, depth);  // the shaders have had the children's time
+        }
         res = node_finish(P, sumf, k_r, k_t, c_refl, c_refr);
         if constexpr (DBG) {
             const uint32_t h = fr[F_H * 64];
@@ -1502,19 +1751,39 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
     const uint32_t cost = valid ? P.tile_cost[t] : 0u;
     const uint32_t bits = 32u - (uint32_t)__builtin_clz(cost | 1u);
     const uint32_t cls = !traced ? kCostClasses : (bits <= 13u ? 0u : (bits - 13u > kCostClasses - 1u ? kCostClasses - 1u : bits - 13u));
+    // Heavy tiles (Params::heavy): a tile on this launch's heavy list is render_heavy_kernel's, which is
+    // tracing it on the second stream already: it is neither listed nor painted here.  (Its cost word may be
+    // rewritten by that kernel while this thread reads it: either value will do, costs only order things.)
+    const bool heavy_now = valid && (P.heavy_now != 0u) && (P.heavy_mark[t] == P.heavy_now);
+    // ... and the next launch's list: the traced tiles whose cost class is at least heavy_class (one class
+    // less for a tile that is on the list already: its three-wave cost is scaled back to one-wave terms
+    // only roughly, and a tile should not change sides every frame)
+    const uint32_t fit_class = P.queue[kHeavyClassWord];  // classify_tiles: the classes from here up fit the side kernel
+    const uint32_t min_class = P.heavy_class > fit_class ? P.heavy_class : fit_class;
+    const bool heavy_next = traced && (P.heavy_next != 0u) && (cls + (heavy_now ? 1u : 0u) >= min_class);
     // block-aggregated append to the class's list: one atomicAdd per block and class (same-address
-    // atomics are the slow part: ~3 ns each, device-wide)
-    __shared__ uint32_t n_cls[kCostClasses + 1], base_cls[kCostClasses + 1];
-    if (threadIdx.x <= kCostClasses) n_cls[threadIdx.x] = 0u;
+    // atomics are the slow part: ~3 ns each, device-wide); slot kCostClasses + 1 = the next heavy list
+    __shared__ uint32_t n_cls[kCostClasses + 2], base_cls[kCostClasses + 2];
+    if (threadIdx.x <= kCostClasses + 1u) n_cls[threadIdx.x] = 0u;
     __syncthreads();
-    uint32_t rank = 0u;
+    uint32_t rank = 0u, hrank = 0u;
     // a prefilled frame (Params::prefilled) needs no painting: tiles that are not traced are not listed
-    const bool listed = in_band && (traced || P.prefilled == 0u);
+    const bool listed = in_band && !heavy_now && (traced || P.prefilled == 0u);
     if (listed) rank = atomicAdd(&n_cls[cls], 1u);
+    if (heavy_next) hrank = atomicAdd(&n_cls[kCostClasses + 1u], 1u);
     __syncthreads();
     if (threadIdx.x <= kCostClasses) base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[P.qsel * 16u + threadIdx.x], n_cls[threadIdx.x]) : 0u;
+    if (threadIdx.x == kCostClasses + 1u)
+        base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[(P.qsel ^ 1u) * 16u + kHeavyCountWord], n_cls[threadIdx.x]) : 0u;
     __syncthreads();
     if (listed) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (no_cubes ? kEntryNoCubes : 0u) | (by << 16);
+    if (heavy_next) {
+        const uint32_t slot = base_cls[kCostClasses + 1u] + hrank;
+        if (slot < kHeavyCap) {  // a longer list is cut: the tiles beyond it stay with render_kernel (no mark)
+            P.heavy[(P.qsel ^ 1u) * kHeavyCap + slot] = bx | (by << 16);
+            P.heavy_mark[t] = P.heavy_next;
+        }
+    }
     // ... except for the reference's never-painted pixel i == width (render.rs:316-322; row 1, column 0): it is 0
     // whether its tile is traced (the render kernel writes 0 there too) or sky
     if (P.prefilled == 1u && t == 0u && P.part == 0u && P.y0 <= 1u && 1u < P.y1 && P.out) P.out[(size_t)(1u - P.y0) * P.width] = 0u;
@@ -1524,7 +1793,7 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
     // the render kernel writes.  (The host chooses this only for a 16-byte aligned buffer and width % 4 == 0.)
     if (P.prefilled == 2u) {
         __shared__ uint8_t paint[1024];
-        paint[threadIdx.x] = (in_band && !traced) ? 1u : 0u;
+        paint[threadIdx.x] = (in_band && !traced && !heavy_now) ? 1u : 0u;
         __syncthreads();
         const uint32_t t0 = blockIdx.x * 1024u;
         for (uint32_t j = threadIdx.x; j < 2048u; j += 1024u) {
@@ -1664,7 +1933,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
                     cnt.v[2] += tests; cnt.v[7] += tests;
                 }
             } else {
-                c = trace_tree<DBG, COUNT, LARGE, DARK>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt PROF_PASS);
+                const Mailbox none{nullptr, nullptr, nullptr};
+                c = trace_tree<DBG, COUNT, LARGE, DARK>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt, none PROF_PASS);
             }
             if (pass == PASS_SPHERES) { px = c; hs = hh; hit_s = hi; }
             else { px = (px == P.sky) ? c : px; hc = hh; hit_c = hi; }
@@ -1712,6 +1982,160 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PE
     }
 }
 
+// ---------------------------------------------------------------- render_heavy_kernel (heavy tiles of a plain frame)
+// Launched on the context's second stream, concurrently with the frame's classification, listing and
+// render_kernel: workgroups of three waves striding over the launch's heavy list (Params::heavy), the three
+// waves as tracer and shaders (see "heavy tiles" above).  Every pixel is computed by trace_tree, as in
+// render_kernel.  The list was written by the previous launch's build_queue, for whatever camera that launch
+// had: an entry only says "trace this tile", so the cube pass is never skipped here.
+template <bool LARGE, bool DARK, bool ASYNC>
+DEV void plain_tile(const Params& P, uint32_t entry, uint32_t* stk, const Mailbox& mb, uint32_t cost_scale)
+{
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    const uint32_t lane = threadIdx.x & 63u;
+    const float width = (float)P.width, height = (float)P.height;
+    const float aspect = width / height;
+    const V3 right = v3(P.right[0], P.right[1], P.right[2]);
+    const V3 up = v3(P.up[0], P.up[1], P.up[2]);
+    const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
+    const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
+    const uint32_t bx = entry & 0x7FFFu, by = entry >> 16;
+    const uint32_t ty0 = tile_y0(P, by);
+    const uint32_t x = bx * 8u + (lane & 7u);
+    const uint32_t y = ty0 + (lane >> 3);
+    const uint32_t out_row = by * 8u + (lane >> 3);
+    const bool active = (x < P.width) && (y < P.y1);  // lanes outside the frame stay in the wave, inactive
+    // render.rs:298-312 (see render_kernel)
+    const bool skip_s = (P.n_spheres == 0u);
+    const bool skip_c = (entry & kEntryNoCubes) != 0u;
+    V3 dir = v3(0.0f, 0.0f, 0.0f);
+    if (!(skip_s && skip_c)) {
+        float sx = (2.0f * (float)x) / width - 1.0f;
+        const float sy = -(2.0f * (float)y) / height + 1.0f;
+        sx = sx * aspect;
+        const V3 v = vnormalize(v3(sx, sy, -1.0f));
+        dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));  // camera.rs:38-40
+    }
+    uint32_t px = 0u;
+    Totals unused;
+    PROF_DECL
+    for (uint32_t pass = PASS_SPHERES; pass <= PASS_CUBES; ++pass) {
+        uint32_t hh, hi, c;
+        const bool skip = (pass == PASS_SPHERES) ? skip_s : skip_c;
+        if (skip) c = P.sky;
+        else c = trace_tree<false, false, LARGE, DARK, ASYNC>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, unused, mb PROF_PASS);
+        if (pass == PASS_SPHERES) px = c;
+        else px = (px == P.sky) ? c : px;
+    }
+    const size_t i_frame = (size_t)y * P.width + x;
+    if (i_frame == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
+    if (active && P.out) P.out[(size_t)out_row * P.width + x] = px;
+    // cycles the tile took, in one-wave terms (a heavy tile's three waves shorten it by about cost_scale)
+    if (lane == 0u) {
+        const unsigned long long cyc = (__builtin_readcyclecounter() - t_start) * cost_scale;
+        P.tile_cost[(size_t)by * P.grid_tx + bx] = (uint32_t)(cyc > 0xFFFFFFFFull ? 0xFFFFFFFFull : cyc) | 1u;
+    }
+}
+
+// A shader wave's part of one heavy item: serve the nodes the tracer posts until it reports the item done.
+template <bool LARGE>
+DEV void shader_serve(const Params& P, const Mailbox& mb, uint32_t w, uint32_t items_target)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t spins = 0u;
+    for (;;) {
+        uint32_t k = kMailDepth;
+        for (uint32_t j = kMailDepth; j-- > 0u;) {
+            const uint32_t pj = lds_load_acquire(&mb.ctl->posted[j]);
+            if (pj != mb.ctl->done[j][w]) k = j;  // done[j][w] is this wave's own word
+        }
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        if (k == kMailDepth) {
+            // nothing posted: the item is over once the tracer says so (it collects every node it posted first)
+            if (lds_load_acquire(&mb.ctl->items_done) >= items_target) return;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) { mb.ctl->error = 2u; return; }
+            continue;
+        }
+        spins = 0u;
+#ifdef RTX_PROFILE
+        const uint32_t prof_c0 = (uint32_t)__builtin_readcyclecounter();
+#endif
+        const uint32_t seq = mb.ctl->posted[k];
+        const uint32_t* r = mb.rec + k * (kRecWords * 64u) + lane;
+        const V3 hit_p = v3(__builtin_bit_cast(float, r[0 * 64]), __builtin_bit_cast(float, r[1 * 64]), __builtin_bit_cast(float, r[2 * 64]));
+        const V3 hit_n = v3(__builtin_bit_cast(float, r[3 * 64]), __builtin_bit_cast(float, r[4 * 64]), __builtin_bit_cast(float, r[5 * 64]));
+        const V3 view_dir = v3(__builtin_bit_cast(float, r[6 * 64]), __builtin_bit_cast(float, r[7 * 64]), __builtin_bit_cast(float, r[8 * 64]));
+        const Col tx_a = col_from_hex(r[9 * 64]);
+        const uint32_t mw = r[10 * 64];
+        const uint32_t hit_id = r[11 * 64];
+        const uint32_t key = r[12 * 64];
+        const bool lit = (mw & 0x80000000u) != 0u;
+        const MatRec m = P.mats[mw & 0x7FFFFFFFu];
+        const float k_ds = 1.0f - m.reflectivity - m.transparency;  // the expression of trace_tree
+        const uint32_t pass = mb.ctl->pass_ambient[k][0];
+        const float ambient = __builtin_bit_cast(float, mb.ctl->pass_ambient[k][1]);
+        Col sum = Col{0.0f, 0.0f, 0.0f};
+        Counters cnt = {};
+        uint32_t h = 0u;
+        PROF_DECL
+        for (uint32_t li = w; li < P.n_lights; li += kShaders) {
+            const Col term = light_term<false, false, LARGE, true>(P, pass, li, lit, lit, hit_p, hit_n, hit_id, view_dir, tx_a, m.specular, m.albedo1, k_ds, ambient, h, cnt, key PROF_PASS);
+            sum = col_add(sum, term);
+        }
+        mb.res[(k * kShaders + w) * 64u + lane] = col_to_hex(sum);
+#ifdef RTX_PROFILE
+        if (lane == 0u) { mb.ctl->prof_busy[w] += (uint32_t)__builtin_readcyclecounter() - prof_c0; mb.ctl->prof_nodes[w] += 1u; }
+#endif
+        lds_store_release(&mb.ctl->done[k][w], seq);
+    }
+}
+
+constexpr uint32_t kHeavyCostScale = 3u;
+#ifndef RTX_HEAVY_WAVES_PER_EU
+#define RTX_HEAVY_WAVES_PER_EU 2  // 256 registers, nothing spilled on the critical path (1080p frame 0.090 -> 0.080 ms against 4)
+#endif
+template <bool LARGE, bool DARK>
+__global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(RTX_HEAVY_WAVES_PER_EU, RTX_HEAVY_WAVES_PER_EU))) void render_heavy_kernel(const Params P)
+{
+    constexpr uint32_t kFrame = kStackDepth * frame_words<false, true>() * 64;
+    __shared__ uint32_t stk[kFrame];      // the tracer's frame stack
+    __shared__ uint32_t mail[kMailWords]; // records and partial sums, see Mailbox
+    __shared__ MailCtl ctl;
+    const uint32_t wave = threadIdx.x >> 6;
+    if (threadIdx.x < sizeof(MailCtl) / 4u) ((uint32_t*)&ctl)[threadIdx.x] = 0u;
+    __syncthreads();  // the only workgroup barrier: from here on the waves meet through the mailbox
+    const Mailbox mb{mail, mail + kMailDepth * kRecWords * 64u, &ctl};
+    KCONST uint32_t* q = (KCONST uint32_t*)P.queue;
+    const uint32_t listed = q[P.qsel * 16u + kHeavyCountWord];
+    const uint32_t n_heavy = listed < kHeavyCap ? listed : kHeavyCap;
+    KCONST uint32_t* list = (KCONST uint32_t*)P.heavy + P.qsel * kHeavyCap;
+    uint32_t items = 0u;
+    for (uint32_t item = blockIdx.x; item < n_heavy; item += gridDim.x) {
+        ++items;
+        if (wave == 0u) {
+            const uint32_t entry = list[item] & ~kEntryNoCubes;
+#ifdef RTX_PROFILE
+            const uint32_t prof_c0 = (uint32_t)__builtin_readcyclecounter();
+            if (threadIdx.x == 0u) { ctl.prof_wait = 0u; for (uint32_t w = 0; w < kShaders; ++w) { ctl.prof_busy[w] = 0u; ctl.prof_nodes[w] = 0u; } }
+#endif
+            plain_tile<LARGE, DARK, true>(P, entry, stk, mb, kHeavyCostScale);
+#ifdef RTX_PROFILE
+            if (threadIdx.x == 0u && P.counters) {
+                uint32_t* slot = (uint32_t*)P.counters + 64 + ((size_t)(entry >> 16) * P.grid_tx + (entry & 0x7FFFu)) * 40u;
+                slot[0] = (uint32_t)__builtin_readcyclecounter() - prof_c0;
+                slot[1] = ctl.prof_wait;
+                for (uint32_t w = 0; w < kShaders; ++w) { slot[2 + w] = ctl.prof_busy[w]; slot[4 + w] = ctl.prof_nodes[w]; }
+            }
+#endif
+            lds_store_release(&ctl.items_done, items);
+        } else {
+            shader_serve<LARGE>(P, mb, wave - 1u, items);
+        }
+    }
+    if (threadIdx.x == 0u && ctl.error != 0u) P.queue[kQueueBase - 1u] = ctl.error;  // header word 63: rt_debug_status
+}
+
 // ---------------------------------------------------------------- classify_tiles
 // Which 8x8 pixel tiles can contain a primary ray that meets a cube?  A pixel's ray is the line
 // eye + t (sx right + sy up + fwd) with sx = (2x/W - 1) W/H, sy = 1 - 2y/H (render.rs:245-262,
@@ -1726,7 +2150,22 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
 {
     const uint32_t cube = blockIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
-    if (cube == 0u && lane < 16u) T.queue[(T.qsel ^ 1u) * 16u + lane] = 0u;  // the queue header bank of the NEXT launch
+    if (cube == 0u) {
+        // The other header bank still holds the previous launch's counts: from them, the lowest cost class
+        // whose tiles and all heavier ones fit the side kernel (kHeavyTarget workgroups at once), for this
+        // launch's build_queue (header word kHeavyClassWord).  The tiles that were on the previous launch's heavy
+        // list are not in its class counts: they count as heavier than everything.
+        uint32_t acc = T.queue[(T.qsel ^ 1u) * 16u + kHeavyCountWord];
+        acc = acc < kHeavyCap ? acc : kHeavyCap;
+        uint32_t cls = kCostClasses;
+        for (uint32_t k = kCostClasses; k-- > 0u;) {
+            acc += T.queue[(T.qsel ^ 1u) * 16u + k];
+            if (acc <= kHeavyTarget && cls == k + 1u) cls = k;
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // the reads above come before the stores below (same wave, in order anyway)
+        if (lane == 0u) T.queue[kHeavyClassWord] = cls;
+        if (lane < 16u) T.queue[(T.qsel ^ 1u) * 16u + lane] = 0u;  // the queue header bank of the NEXT launch
+    }
     if (cube >= T.n_cubes) return;
     const float* rec = T.cube_filt + (size_t)cube * 4u;
     const double h = __builtin_fabs((double)rec[3]) + T.pad;
@@ -1865,6 +2304,22 @@ int launch_render(const Params& p, int variant, void* stream, uint32_t max_workg
             else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, 0, s, p);
         }
         break;
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_heavy(const Params& p, void* stream)
+{
+    if (p.grid_tx * p.grid_ty == 0u || !p.heavy) return (int)hipSuccess;
+    dim3 grid(kHeavyGrid, 1u, 1u), block(64u * kWgWaves, 1u, 1u);
+    hipStream_t s = (hipStream_t)stream;
+    const bool large = p.n_chunks > 0u;
+    if (p.dark_materials != 0u) {
+        if (large) hipLaunchKernelGGL((render_heavy_kernel<true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((render_heavy_kernel<false, true>), grid, block, 0, s, p);
+    } else {
+        if (large) hipLaunchKernelGGL((render_heavy_kernel<true, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((render_heavy_kernel<false, false>), grid, block, 0, s, p);
     }
     return (int)hipGetLastError();
 }

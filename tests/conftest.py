@@ -34,7 +34,13 @@ def water_scene():
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    """The session's context.  RTX950_TEST_HEAVY_CLASS=k (read HERE, by the test harness: the library reads no
+    environment) soaks the whole suite with every tile of cost class >= k on three-wave workgroups (0 = all)."""
     import raytracing_amd as rt
+    if os.environ.get("RTX950_TEST_HEAVY_CLASS"):
+        rt.Context.DEFAULT_TUNING[rt.RT_TUNE_HEAVY_CLASS] = int(os.environ["RTX950_TEST_HEAVY_CLASS"])
     ctx = rt.Context(0)
+    ctx.reset_tuning()
     yield ctx
+    assert ctx.debug_status() == 0, "a heavy tile's workgroup gave up waiting for its partners"
     ctx.close()

@@ -482,8 +482,90 @@ def test_render_into_pinned_memory(gpu_ctx, default_scene):
         pin.close()
 
 
+@pytest.mark.parametrize("heavy", [0, 2, 8, -1])
+def test_heavy_tiles_on_three_waves(tuned_ctx, oracle_mod, default_scene, water_scene, heavy):
+    """RT_TUNE_HEAVY_CLASS: tiles of cost class >= the key (costs of the context's previous launch) are traced
+    by render_heavy_kernel on the second stream - a workgroup of three waves per tile, a tracer that posts each
+    node's light fold to two shader waves, the general cull, bundles walked one by one - and the others by
+    render_kernel.  As many tiles as fit (0), the expensive ones (2), none (8), automatic (-1: on for the
+    synchronous rt_render of a small frame): the frame is the debug variant's (one wave per tile, inline fold)
+    and the oracle's, for the diorama, the water variant (two children per node), a long list with spheres,
+    1 and 3 and 16 lights, and repeated launches (the second and later ones use the list the one before wrote)."""
+    ctx = tuned_ctx
+    ctx.set_tuning(rt.RT_TUNE_HEAVY_CLASS, heavy)
+    s = default_scene
+    lights16 = [rt.Light(rt.Vec3(-8.0 + k, 6.0 + 0.5 * k, 9.0 - 1.3 * k), 0x102030 * (k % 7 + 1) & 0xFFFFFF, 0.05 + 0.07 * k) for k in range(16)]
+    many = rt.make_scene(list(s.cubes), [], list(s.materials), lights16, s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
+    one = rt.make_scene(list(s.cubes), [], list(s.materials), lights16[:1], s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
+    three = rt.make_scene(list(s.cubes), [], list(s.materials), lights16[:3], s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
+    syn = rt.synthetic_scene(n_cubes=1500, n_spheres=12)
+    for sc, w, h in ((s, 480, 270), (water_scene, 480, 270), (syn, 320, 180), (one, 160, 96), (three, 160, 96), (many, 160, 96)):
+        f, gfb, gpl, ofb, opl, ocnt = _both(ctx, oracle_mod, sc, w, h)
+        assert_parity(gfb, gpl, ofb, opl, f"heavy class {heavy}: {sc.name} {w}x{h}")
+        for _ in range(3):  # the plain launches' own tile costs now select the heavy tiles
+            assert np.array_equal(ctx.render(f), gfb)
+        assert ctx.debug_status() == 0
+    if heavy == 0:
+        costs = ctx.tile_costs()
+        assert (costs > 0).any()
+
+
+def test_heavy_tiles_asynchronous_entry_points(tuned_ctx, default_scene, water_scene):
+    """The side kernel behind rt_render_device / rt_render_device_part: the heavy list a launch uses was written
+    by the launch before it, for that launch's camera - a moving camera, a changed frame size (the list is then
+    dropped), the parts of a split, frames queued back to back into one buffer without a host wait (the side
+    stream is fenced against the context's stream both ways), a debug launch in between.  Every frame equals
+    the one the same context renders with the side kernel off."""
+    import torch
+    ctx = tuned_ctx
+    for scene in (default_scene, water_scene):
+        ctx.upload(scene)
+        cams = []
+        for k in range(6):
+            c = rt.Camera(); C0 = scene.camera
+            c.eye = rt.Vec3(C0.eye.x + 0.7 * k, C0.eye.y + 0.3 * k, C0.eye.z - 0.5 * k); c.center = C0.center; c.up = C0.up
+            cams.append(c)
+        sizes = [(480, 272), (480, 272), (480, 272), (320, 200), (320, 200), (480, 272)]
+        frames = [scene.frame(w, h, camera=c) for (w, h), c in zip(sizes, cams)]
+        ctx.set_tuning(rt.RT_TUNE_HEAVY_CLASS, 8)
+        want = [ctx.render(f) for f in frames]
+        for heavy in (0, 3):
+            ctx.set_tuning(rt.RT_TUNE_HEAVY_CLASS, heavy)
+            # 1. one buffer per frame, everything queued, one wait at the end
+            outs = [torch.zeros((f.height, f.width), dtype=torch.int32, device="cuda") for f in frames]
+            torch.cuda.synchronize()
+            for rep in range(2):
+                for f, o in zip(frames, outs):
+                    ctx.render_device(f, o.data_ptr())
+            ctx.sync()
+            for f, o, wnt in zip(frames, outs, want):
+                assert np.array_equal(o.cpu().numpy().view(np.uint32), wnt), f"heavy {heavy}: {scene.name} {f.width}x{f.height}"
+            # 2. the same camera again and again into ONE buffer, a debug launch in between, no host wait
+            f = frames[0]
+            o = outs[0]
+            hc = torch.zeros_like(o)
+            for rep in range(5):
+                ctx.render_device(f, o.data_ptr())
+                if rep == 2:
+                    ctx.render_device(f, o.data_ptr(), d_hit_cube=hc.data_ptr())
+            ctx.sync()
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), want[0])
+            # 3. the parts of a 3-way split, three frames each
+            f = frames[1]
+            for part in range(3):
+                rows = rt.part_rows(f.y1 - f.y0, 3, part)
+                po = torch.zeros((rows, f.width), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                for rep in range(3):
+                    ctx.render_device(f, po.data_ptr(), n_parts=3, part=part)
+                ctx.sync()
+                idx = rt.part_row_indices(f.y1 - f.y0, 3, part)
+                assert np.array_equal(po.cpu().numpy().view(np.uint32), want[1][idx]), f"heavy {heavy}: part {part}"
+            assert ctx.debug_status() == 0
+
+
 def test_tuning_keys_are_validated(gpu_ctx):
-    for key, bad in ((rt.RT_TUNE_COHERENT_SCALE, -1.0), (rt.RT_TUNE_SHADOW_LIST, 2), (rt.RT_TUNE_DARK_KERNEL, 0.5), (rt.RT_TUNE_FILL_MEMSET, -1), (99, 0)):
+    for key, bad in ((rt.RT_TUNE_HEAVY_CLASS, 9), (rt.RT_TUNE_HEAVY_CLASS, -2), (rt.RT_TUNE_HEAVY_CLASS, 2.5), (rt.RT_TUNE_COHERENT_SCALE, -1.0), (rt.RT_TUNE_SHADOW_LIST, 2), (rt.RT_TUNE_DARK_KERNEL, 0.5), (rt.RT_TUNE_FILL_MEMSET, -1), (99, 0)):
         with pytest.raises(rt.RtError) as e:
             gpu_ctx.set_tuning(key, bad)
         assert e.value.code == rt._ffi.RT_ERR_INVALID_ARG
