@@ -25,7 +25,9 @@ using namespace rtx950;
 
 // Heavy tiles, automatic mode: tiles of >= 128 K cycles (one-wave terms) go to render_heavy_kernel on the second
 // stream when the call is the synchronous rt_render (one frame at a time by construction: the frame's slowest
-// tile is its duration) and the launch is small enough to be bound by that tile rather than by throughput.
+// tile is its duration), the launch is small enough to be bound by that tile rather than by throughput, and
+// the cube list is a short one (the slow tiles of a long list are per-lane BVH walks, which three waves do
+// not shorten: 10k-cube world 1.55 -> 1.76 ms with the side kernel).
 // The side stream costs about 12 us per frame in event traffic, and a process that keeps several contexts'
 // frames in flight has more streams than hardware queues (a waiting side kernel then blocks another context's
 // launches): asynchronous callers opt in with RT_TUNE_HEAVY_CLASS.
@@ -78,10 +80,10 @@ static DeviceScratch g_dev_scratch[kMaxDevices];
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    // render_heavy_kernel runs here, between an event recorded on `stream` when the call begins and one that
-    // `stream` waits for after its own launches: callers see one stream, as before
+    // render_heavy_kernel runs here.  It starts when classify_tiles of the same launch, on `stream`, says so, and
+    // `stream` meets it again in the heavy_join kernel behind its own launches (words in the queue header,
+    // no events): callers see one stream, as before
     hipStream_t stream_heavy = nullptr;
-    hipEvent_t heavy_fork = nullptr, heavy_join = nullptr;
     std::string err;
     // scene
     bool has_scene = false;
@@ -362,8 +364,9 @@ int grow(rt_ctx* ctx, TileScratch& ts, uint32_t** buf, size_t* cap, size_t need,
     return RT_OK;
 }
 
-int prepare(rt_ctx* ctx, Params& p, TileScratch& ts)
+int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint32_t heavy_go = 0u, bool* out_classified = nullptr)
 {
+    if (out_classified) *out_classified = false;
     p.tile_stamps = nullptr;
     p.tiles_x = (p.width + 7u) / 8u;
     p.tiles_y = (p.height + 7u) / 8u;
@@ -411,6 +414,8 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts)
     t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y;
     t.queue = ts.queue;
     t.qsel = p.qsel;
+    t.heavy_on = heavy_on ? 1u : 0u;
+    t.heavy_go = heavy_go;
     if (++ts.frame_id == 0u) {  // wrapped: stale stamps could alias, start over
         HIP_TRY(ctx, hipMemsetAsync(ts.stamps, 0, ts.stamps_cap * sizeof(uint32_t), ctx->stream));
         ts.frame_id = 1u;
@@ -421,6 +426,7 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts)
     if (e != hipSuccess) return fail_hip(ctx, e, "classify kernel launch");
     p.tile_stamps = ts.stamps;
     p.frame_id = ts.frame_id;
+    if (out_classified) *out_classified = true;
     return RT_OK;
 }
 
@@ -483,22 +489,11 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
         delete c;
         return fail_hip(nullptr, e, "hipStreamCreateWithFlags");
     }
-    {
-        // the side stream gets the highest priority there is: its few workgroups are the frame's critical path
-        int prio_least = 0, prio_greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        e = hipStreamCreateWithPriority(&c->stream_heavy, hipStreamNonBlocking, prio_greatest);
-    }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->heavy_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->heavy_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, kCounterBytes);
+    e = hipMalloc((void**)&c->d_counters, kCounterBytes);
     if (e != hipSuccess) {
-        if (c->heavy_join) (void)hipEventDestroy(c->heavy_join);
-        if (c->heavy_fork) (void)hipEventDestroy(c->heavy_fork);
-        if (c->stream_heavy) (void)hipStreamDestroy(c->stream_heavy);
         (void)hipStreamDestroy(c->stream);
         delete c;
-        return fail_hip(nullptr, e, "rt_ctx_create: second stream, events or counter buffer");
+        return fail_hip(nullptr, e, "hipMalloc(counters)");
     }
     // The fixed work buffer of rt_render_device_noalloc: this device's copy of `scratch`, looked up once per
     // device with the device current (in host code the array's name is not a device address).
@@ -510,9 +505,6 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
             e = hipGetSymbolAddress((void**)&base, HIP_SYMBOL(scratch));
             if (e != hipSuccess || !base) {
                 (void)hipFree(c->d_counters);
-                (void)hipEventDestroy(c->heavy_join);
-                (void)hipEventDestroy(c->heavy_fork);
-                (void)hipStreamDestroy(c->stream_heavy);
                 (void)hipStreamDestroy(c->stream);
                 delete c;
                 return fail_hip(nullptr, e, "hipGetSymbolAddress(scratch)");
@@ -536,7 +528,7 @@ int rt_ctx_destroy(rt_ctx* ctx)
     if (!ctx) return RT_OK;
     DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream_heavy);
+    if (ctx->stream_heavy) (void)hipStreamSynchronize(ctx->stream_heavy);
     free_scene(ctx);
     (void)hipFree(ctx->d_fb);
     for (auto& b : ctx->d_dbg) (void)hipFree(b);
@@ -550,9 +542,7 @@ int rt_ctx_destroy(rt_ctx* ctx)
     if (ctx->part_done) (void)hipEventDestroy(ctx->part_done);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    (void)hipEventDestroy(ctx->heavy_join);
-    (void)hipEventDestroy(ctx->heavy_fork);
-    (void)hipStreamDestroy(ctx->stream_heavy);
+    if (ctx->stream_heavy) (void)hipStreamDestroy(ctx->stream_heavy);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -845,6 +835,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.n_bvh_nodes = (uint32_t)nodes.size();
     b.coherent_thr = half_n ? (float)(8.0 * half_sum / (double)half_n) : 0.0f;  // 8 average half sizes (swept with the ordered walk: 4..16 within 10 %)
     b.split_thr = half_n ? (float)(0.5 * half_sum / (double)half_n) : 0.0f;  // heavy tiles: half an average half size of inflation per cube
+    b.bvh_levels = std::min(std::max(bvh_depth, 1u), kBvhStackMax);
     if (bvh_depth > ctx->tune_bvh_depth_limit) b.coherent_thr = INFINITY;  // a list too long for the walk's per-lane stack: every wave takes the chunk traversal
     if (std::isfinite(b.coherent_thr)) b.coherent_thr *= ctx->tune_coherent_scale;  // rt_set_tuning: 1 unless a test forces one traversal
     b.spheres = ctx->d_spheres;
@@ -927,22 +918,26 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     const bool paints = ((uintptr_t)d_out_0rgb & 15u) == 0u && (frame->width & 3u) == 0u && !ctx->tune_fill_memset;
     const size_t launch_tiles = (size_t)((frame->width + 7u) / 8u) * ((rt_part_rows(frame->y1 - frame->y0, n_parts, part) + 7u) / 8u);
     const uint32_t heavy_class = ctx->tune_heavy_class >= 0 ? (uint32_t)ctx->tune_heavy_class
-                                 : ((synchronous && launch_tiles <= kAutoHeavyMaxTiles) ? kDefaultHeavyClass : kCostClasses);
+                                 : ((synchronous && launch_tiles <= kAutoHeavyMaxTiles && ctx->base.n_chunks == 0u) ? kDefaultHeavyClass : kCostClasses);
     const bool heavy_on = variant == kVariantRender && paints && heavy_class < kCostClasses;
     const uint32_t seq = ts.launch_seq;  // this launch's; prepare() increments it
     const uint32_t geom[6] = {frame->width, frame->height, frame->y0, frame->y1, n_parts, part};
-    bool heavy_fork = false;
+    if (heavy_on && !ctx->stream_heavy) {
+        // created on first use: a context that never takes this path keeps to one stream (a process has few
+        // hardware queues, and streams beyond them share).  The highest priority there is: the side kernel's few
+        // workgroups are the frame's critical path.
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream_heavy, hipStreamNonBlocking, prio_greatest));
+    }
     bool heavy_now = heavy_on && ts.heavy_list_ready && ts.heavy_list_seq == seq && std::memcmp(ts.heavy_geom, geom, sizeof(geom)) == 0 &&
                      seq + 1u != 0u;
-    if (heavy_now) {
-        // everything enqueued on the context's stream so far (the caller's use of the output buffer included)
-        // comes before the side kernel; this launch's own kernels do not.  An idle stream needs no event.
-        heavy_fork = hipStreamQuery(ctx->stream) != hipSuccess;
-        (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error
-        if (heavy_fork) HIP_TRY(ctx, hipEventRecord(ctx->heavy_fork, ctx->stream));
-    }
-    if ((rc = prepare(ctx, p, ts)) != RT_OK) return rc;
-    heavy_now = heavy_now && ts.heavy_list_ready;  // a buffer that had to grow took the list with it
+    // classify_tiles of this launch tells the side kernel when to start (kHeavyGoWord): no event between the streams
+    bool classified = false;
+    if ((rc = prepare(ctx, p, ts, heavy_on, heavy_now ? seq + 1u : 0u, &classified)) != RT_OK) return rc;
+    // a buffer that had to grow took the list with it (no mark can match then: the fresh marks are zero), and
+    // without classify_tiles (irregular camera) nobody would say go
+    heavy_now = heavy_now && ts.heavy_list_ready && classified;
     ts.heavy_list_ready = false;
     if (heavy_on) {
         p.heavy = ts.heavy;
@@ -973,12 +968,11 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     }
     if ((rc = launch_timed(ctx, p, variant)) != RT_OK) return rc;
     if (heavy_now) {
-        // after the stream's own launches, so that the host's time for these four calls is not ahead of them
-        if (heavy_fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_heavy, ctx->heavy_fork, 0));
+        // after the stream's own launches, so that the host's time for these calls is not ahead of them
         hipError_t e = (hipError_t)launch_heavy(p, (void*)ctx->stream_heavy);
         if (e != hipSuccess) return fail_hip(ctx, e, "heavy kernel launch");
-        HIP_TRY(ctx, hipEventRecord(ctx->heavy_join, ctx->stream_heavy));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->heavy_join, 0));  // the frame is whole when the stream gets here
+        e = (hipError_t)launch_heavy_join(p, (void*)ctx->stream);  // the frame is whole when the stream gets past this
+        if (e != hipSuccess) return fail_hip(ctx, e, "heavy join launch");
     }
     return RT_OK;
 }

@@ -160,14 +160,22 @@ struct Params {
     uint32_t* heavy_mark;
     uint32_t heavy_now, heavy_next;
     uint32_t heavy_class;
+    // levels of the per-lane stack of cube_query_bvh that the launch allocates (dynamic LDS, 256 B a level and
+    // wave): the depth of the scene's BVH, at most kBvhStackMax.  14 levels for 10 000 cubes: with the stack at
+    // its full 28 levels the long-list kernels held 2 waves per SIMD, now 3 (10k-cube world, two frames in
+    // flight: 1.23 -> 0.94 ms)
+    uint32_t bvh_levels;
     float split_thr;  // heavy tiles: a wave whose cull inflation exceeds this is walked bundle by bundle (cube_query, SPLIT)
 };
 constexpr uint32_t kHeavyCap = 1024;       // heavy tiles per launch; the rest stay with render_kernel
 constexpr uint32_t kHeavyTarget = 512;     // classify_tiles raises the class threshold until about this many tiles qualify:
                                            // what the side kernel's three-wave workgroups can hold at once beside render_kernel
 constexpr uint32_t kHeavyCountWord = 9;    // word of a queue header bank that counts the heavy list's entries
+constexpr uint32_t kHeavyDoneWord = 10;    // ... and the one that counts the entries render_heavy_kernel has finished
+constexpr uint32_t kHeavyGoWord = 48;      // queue header word (a cache line of its own): classify_tiles stores the launch's heavy_now
+                                           // here, render_heavy_kernel starts its tiles when it reads it
 constexpr uint32_t kHeavyClassWord = 62;   // queue header word: the lowest class that fits (classify_tiles -> build_queue)
-constexpr uint32_t kHeavyGrid = 640;       // workgroups of render_heavy_kernel (striding over the list)
+constexpr uint32_t kHeavyGrid = 576;       // workgroups of render_heavy_kernel (striding over the list)
 
 // classify_tiles: one wave per cube projects the cube's padded corners through the frame's camera and
 // stamps the 8x8 pixel tiles its bounding rectangle touches.  Primary rays of unstamped tiles cannot
@@ -184,6 +192,8 @@ struct TileParams {
     uint32_t frame_id;
     uint32_t* queue;  // block 0 zeroes header bank qsel ^ 1 (the next launch's)
     uint32_t qsel;
+    uint32_t heavy_on;  // the launch keeps a heavy list: block 0 works out which cost classes fit (kHeavyClassWord)
+    uint32_t heavy_go;  // Params::heavy_now of the launch (0: no side kernel): block 0 stores it to queue[kHeavyGoWord]
 };
 constexpr uint32_t kStampBase = 64;  // first per-tile word
 constexpr uint32_t kQueueBase = 64;  // first tile entry of Params::queue
@@ -199,6 +209,9 @@ int launch_queue(const Params& p, int variant, void* stream);
 int launch_render(const Params& p, int variant, void* stream, uint32_t max_workgroups);
 // launch_heavy: render_heavy_kernel for the launch's heavy list (plain frames only), on `stream`
 int launch_heavy(const Params& p, void* stream);
+// launch_heavy_join: one wave on the context's stream that ends when render_heavy_kernel has finished every
+// tile of the launch's list (a kernel behind a kernel costs the stream 2-3 us, an event wait 9)
+int launch_heavy_join(const Params& p, void* stream);
 int launch_classify(const TileParams& t, void* stream);
 // selftest_division: blocks x 256 threads x iters operand pairs; d_out[0] += mismatches, d_out[1] += cases
 int launch_selftest_division(uint32_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out, void* stream);

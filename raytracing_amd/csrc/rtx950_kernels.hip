@@ -1026,11 +1026,12 @@ DEV void cube_query_large(const Params& P, const RayPre& q, const CP& cp, bool a
 // for cubes, the box lies within the scene bounds), subtrees whose lowest list index is not below the
 // blocker.  Unsafe rays have tol = inf and NaN compares false: they visit everything.
 constexpr uint32_t kWgWaves = 3;  // waves of a render_heavy_kernel workgroup (one tracer, two shaders for a heavy tile)
+extern __shared__ uint32_t dyn_lds[];  // [wave][level][lane], Params::bvh_levels levels: launch_render / launch_heavy size it
 template <uint32_t WAVES>
-DEV uint32_t* bvh_stack()
+DEV uint32_t* bvh_stack(const Params& P)
 {
-    __shared__ uint32_t s[WAVES][kBvhStackMax * 64u];  // [wave][level][lane]; only kernels of long lists carry it
-    return s[(threadIdx.x >> 6) % WAVES];
+    if constexpr (WAVES == 1u) return dyn_lds;
+    else return dyn_lds + ((threadIdx.x >> 6) % WAVES) * (P.bvh_levels * 64u);
 }
 
 struct BoxTest { float lo; bool hit; };
@@ -1064,7 +1065,7 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
     PROF_MARK(PH_PRE);
     const uint32_t lane = threadIdx.x & 63u;
     const f32x4* nodes = (const f32x4*)P.bvh;
-    uint32_t* stack = bvh_stack<WAVES>() + lane;
+    uint32_t* stack = bvh_stack<WAVES>(P) + lane;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     uint32_t pair = active ? 0u : kNone;  // pair 0: the children of the root
     uint32_t sp = 0u;
@@ -1736,6 +1737,9 @@ DEV bool tile_has_no_cubes(const Params& P, uint32_t bx, uint32_t ty0)
 // tile whose primary rays can hit nothing (no spheres in the scene and no cube projecting into it) goes
 // to the last list (class kCostClasses): the render kernel paints it without tracing, after all traced
 // tiles have been handed out.  Every other tile goes to the list of its cost class.
+// HEAVY: the launch uses or writes a heavy list (Params::heavy); launches that do neither run the instantiation
+// without that code (with it compiled in, unused, the 4K frame with two frames in flight took 3 % longer).
+template <bool HEAVY>
 __global__ __launch_bounds__(1024) void build_queue(const Params P)
 {
     const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
@@ -1754,30 +1758,39 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
     // Heavy tiles (Params::heavy): a tile on this launch's heavy list is render_heavy_kernel's, which is
     // tracing it on the second stream already: it is neither listed nor painted here.  (Its cost word may be
     // rewritten by that kernel while this thread reads it: either value will do, costs only order things.)
-    const bool heavy_now = valid && (P.heavy_now != 0u) && (P.heavy_mark[t] == P.heavy_now);
+    bool heavy_now = false;
+    if constexpr (HEAVY) heavy_now = valid && (P.heavy_now != 0u) && (P.heavy_mark[t] == P.heavy_now);
     // ... and the next launch's list: the traced tiles whose cost class is at least heavy_class (one class
     // less for a tile that is on the list already: its three-wave cost is scaled back to one-wave terms
     // only roughly, and a tile should not change sides every frame)
-    const uint32_t fit_class = P.queue[kHeavyClassWord];  // classify_tiles: the classes from here up fit the side kernel
-    const uint32_t min_class = P.heavy_class > fit_class ? P.heavy_class : fit_class;
-    const bool heavy_next = traced && (P.heavy_next != 0u) && (cls + (heavy_now ? 1u : 0u) >= min_class);
+    bool heavy_next = false;
+    if (HEAVY && P.heavy_next != 0u) {  // wave-uniform
+        const uint32_t fit_class = P.queue[kHeavyClassWord];  // classify_tiles: the classes from here up fit the side kernel
+        const uint32_t min_class = P.heavy_class > fit_class ? P.heavy_class : fit_class;
+        heavy_next = traced && (cls + (heavy_now ? 1u : 0u) >= min_class);
+    }
     // block-aggregated append to the class's list: one atomicAdd per block and class (same-address
     // atomics are the slow part: ~3 ns each, device-wide); slot kCostClasses + 1 = the next heavy list
-    __shared__ uint32_t n_cls[kCostClasses + 2], base_cls[kCostClasses + 2];
-    if (threadIdx.x <= kCostClasses + 1u) n_cls[threadIdx.x] = 0u;
+    constexpr uint32_t kSlots = kCostClasses + (HEAVY ? 2u : 1u);
+    __shared__ uint32_t n_cls[kSlots], base_cls[kSlots];
+    if (threadIdx.x < kSlots) n_cls[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t rank = 0u, hrank = 0u;
     // a prefilled frame (Params::prefilled) needs no painting: tiles that are not traced are not listed
     const bool listed = in_band && !heavy_now && (traced || P.prefilled == 0u);
     if (listed) rank = atomicAdd(&n_cls[cls], 1u);
-    if (heavy_next) hrank = atomicAdd(&n_cls[kCostClasses + 1u], 1u);
+    if constexpr (HEAVY) {
+        if (heavy_next) hrank = atomicAdd(&n_cls[kCostClasses + 1u], 1u);
+    }
     __syncthreads();
     if (threadIdx.x <= kCostClasses) base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[P.qsel * 16u + threadIdx.x], n_cls[threadIdx.x]) : 0u;
-    if (threadIdx.x == kCostClasses + 1u)
-        base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[(P.qsel ^ 1u) * 16u + kHeavyCountWord], n_cls[threadIdx.x]) : 0u;
+    if constexpr (HEAVY) {
+        if (threadIdx.x == kCostClasses + 1u)
+            base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[(P.qsel ^ 1u) * 16u + kHeavyCountWord], n_cls[threadIdx.x]) : 0u;
+    }
     __syncthreads();
     if (listed) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (no_cubes ? kEntryNoCubes : 0u) | (by << 16);
-    if (heavy_next) {
+    if (HEAVY && heavy_next) {
         const uint32_t slot = base_cls[kCostClasses + 1u] + hrank;
         if (slot < kHeavyCap) {  // a longer list is cut: the tiles beyond it stay with render_kernel (no mark)
             P.heavy[(P.qsel ^ 1u) * kHeavyCap + slot] = bx | (by << 16);
@@ -1824,8 +1837,11 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
 #ifndef RTX_WAVES_PER_EU
 #define RTX_WAVES_PER_EU 4
 #endif
+#ifndef RTX_WAVES_PER_EU_LARGE
+#define RTX_WAVES_PER_EU_LARGE 3  // long lists: per-lane BVH walks want the registers more than the fourth wave (168 instead of 128)
+#endif
 template <bool DBG, bool COUNT, bool LARGE, bool DARK = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PER_EU, RTX_WAVES_PER_EU))) void render_kernel(const Params P)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU, LARGE ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU))) void render_kernel(const Params P)
 {
     __shared__ uint32_t stk[kStackDepth * frame_words<DBG>() * 64];
     const uint32_t lane = threadIdx.x & 63u;
@@ -2029,11 +2045,16 @@ DEV void plain_tile(const Params& P, uint32_t entry, uint32_t* stk, const Mailbo
     }
     const size_t i_frame = (size_t)y * P.width + x;
     if (i_frame == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
-    if (active && P.out) P.out[(size_t)out_row * P.width + x] = px;
+    // The side kernel's stores are device-coherent ones (relaxed atomic stores at agent scope: they go through
+    // to where every XCD reads them), so that a finished tile can be counted behind a wait for these stores
+    // alone: a release fence at agent scope writes the XCD's whole L2 back, per tile, under render_kernel's
+    // own stores (1080p frame +25 %).
+    if (active && P.out) __hip_atomic_store(&P.out[(size_t)out_row * P.width + x], px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // cycles the tile took, in one-wave terms (a heavy tile's three waves shorten it by about cost_scale)
     if (lane == 0u) {
         const unsigned long long cyc = (__builtin_readcyclecounter() - t_start) * cost_scale;
-        P.tile_cost[(size_t)by * P.grid_tx + bx] = (uint32_t)(cyc > 0xFFFFFFFFull ? 0xFFFFFFFFull : cyc) | 1u;
+        __hip_atomic_store(&P.tile_cost[(size_t)by * P.grid_tx + bx], (uint32_t)(cyc > 0xFFFFFFFFull ? 0xFFFFFFFFull : cyc) | 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2106,10 +2127,10 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(R
     if (threadIdx.x < sizeof(MailCtl) / 4u) ((uint32_t*)&ctl)[threadIdx.x] = 0u;
     __syncthreads();  // the only workgroup barrier: from here on the waves meet through the mailbox
     const Mailbox mb{mail, mail + kMailDepth * kRecWords * 64u, &ctl};
-    KCONST uint32_t* q = (KCONST uint32_t*)P.queue;
+    const uint32_t* q = P.queue;
     const uint32_t listed = q[P.qsel * 16u + kHeavyCountWord];
     const uint32_t n_heavy = listed < kHeavyCap ? listed : kHeavyCap;
-    KCONST uint32_t* list = (KCONST uint32_t*)P.heavy + P.qsel * kHeavyCap;
+    const uint32_t* list = P.heavy + P.qsel * kHeavyCap;
     uint32_t items = 0u;
     for (uint32_t item = blockIdx.x; item < n_heavy; item += gridDim.x) {
         ++items;
@@ -2129,11 +2150,53 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(R
             }
 #endif
             lds_store_release(&ctl.items_done, items);
+            // the tile's pixels and cost word are visible device-wide before it counts as finished (heavy_join):
+            // see plain_tile's stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: the wave's stores above have completed
+            if (threadIdx.x == 0u) __hip_atomic_fetch_add(&P.queue[P.qsel * 16u + kHeavyDoneWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             shader_serve<LARGE>(P, mb, wave - 1u, items);
         }
     }
     if (threadIdx.x == 0u && ctl.error != 0u) P.queue[kQueueBase - 1u] = ctl.error;  // header word 63: rt_debug_status
+}
+
+// heavy_gate: the side stream waits here, one wave, until classify_tiles of the same launch says go
+// (kHeavyGoWord; sequence numbers only grow).  The side stream is not fenced against the context's stream by
+// events - an event record costs that stream 10 us per frame - so render_heavy_kernel, which follows this
+// kernel on the side stream, could otherwise start while the previous frame is still being rendered: before
+// the list it reads is complete and before the caller is done with the output buffer.  (Waiting inside
+// render_heavy_kernel itself was tried: its workgroups become resident early and hold half of the register
+// files while they wait; two contexts' worth of them leave no room for the kernel they wait for.)  Every wait
+// between the two streams points at a kernel that was enqueued earlier, so the waits cannot form a cycle.
+__global__ __launch_bounds__(64) void heavy_gate(const Params P)
+{
+    uint32_t spins = 0u;
+    while (__hip_atomic_load(&P.queue[kHeavyGoWord], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != P.heavy_now) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 24)) {
+            if (threadIdx.x == 0u) P.queue[kQueueBase - 1u] = 4u;
+            break;
+        }
+    }
+}
+
+// heavy_join: the context's stream meets the side stream here.  One wave polls the launch's count of
+// finished heavy tiles until it reaches the list's length; the kernel's end then orders everything after it
+// on the stream behind those tiles' stores.  The side kernel needs nothing from this one, so the wait cannot
+// deadlock; a wave that gives up (seconds) reports through rt_debug_status.
+__global__ __launch_bounds__(64) void heavy_join(const Params P)
+{
+    const uint32_t listed = __hip_atomic_load(&P.queue[P.qsel * 16u + kHeavyCountWord], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t want = listed < kHeavyCap ? listed : kHeavyCap;
+    uint32_t spins = 0u;
+    while (__hip_atomic_load(&P.queue[P.qsel * 16u + kHeavyDoneWord], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 24)) {
+            if (threadIdx.x == 0u) P.queue[kQueueBase - 1u] = 3u;
+            break;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- classify_tiles
@@ -2155,15 +2218,24 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
         // whose tiles and all heavier ones fit the side kernel (kHeavyTarget workgroups at once), for this
         // launch's build_queue (header word kHeavyClassWord).  The tiles that were on the previous launch's heavy
         // list are not in its class counts: they count as heavier than everything.
-        uint32_t acc = T.queue[(T.qsel ^ 1u) * 16u + kHeavyCountWord];
-        acc = acc < kHeavyCap ? acc : kHeavyCap;
-        uint32_t cls = kCostClasses;
-        for (uint32_t k = kCostClasses; k-- > 0u;) {
-            acc += T.queue[(T.qsel ^ 1u) * 16u + k];
-            if (acc <= kHeavyTarget && cls == k + 1u) cls = k;
+        // (One load for the whole bank, lane k its word k; the sums run over readlanes.  Launches that keep no
+        // heavy list skip this: heavy_on == 0.)
+        if (T.heavy_on != 0u) {
+            const uint32_t word = lane < 16u ? T.queue[(T.qsel ^ 1u) * 16u + lane] : 0u;
+            uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)kHeavyCountWord);
+            acc = acc < kHeavyCap ? acc : kHeavyCap;
+            uint32_t cls = kCostClasses;
+#pragma unroll
+            for (uint32_t k = kCostClasses; k-- > 0u;) {
+                acc += (uint32_t)__builtin_amdgcn_readlane((int)word, (int)k);
+                if (acc <= kHeavyTarget && cls == k + 1u) cls = k;
+            }
+            if (lane == 0u) T.queue[kHeavyClassWord] = cls;
         }
-        __builtin_amdgcn_s_waitcnt(0);  // the reads above come before the stores below (same wave, in order anyway)
-        if (lane == 0u) T.queue[kHeavyClassWord] = cls;
+        // The side kernel of this launch may start: everything enqueued on the context's stream before this
+        // launch has completed (the previous launch's build_queue, which wrote the list, and whatever the
+        // caller did with the output buffer).  A device-coherent store: the waiting waves run on any XCD.
+        if (lane == 0u && T.heavy_go != 0u) __hip_atomic_store(&T.queue[kHeavyGoWord], T.heavy_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane < 16u) T.queue[(T.qsel ^ 1u) * 16u + lane] = 0u;  // the queue header bank of the NEXT launch
     }
     if (cube >= T.n_cubes) return;
@@ -2273,7 +2345,8 @@ int launch_queue(const Params& p, int variant, void* stream)
     dim3 grid((tiles + 1023u) / 1024u, 1u, 1u), block(1024u, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
     (void)variant;
-    hipLaunchKernelGGL(build_queue, grid, block, 0, s, p);
+    if (p.heavy_now != 0u || p.heavy_next != 0u) hipLaunchKernelGGL(build_queue<true>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(build_queue<false>, grid, block, 0, s, p);
     return (int)hipGetLastError();
 }
 
@@ -2286,22 +2359,23 @@ int launch_render(const Params& p, int variant, void* stream, uint32_t max_workg
     dim3 grid(items < max_workgroups ? items : max_workgroups, 1u, 1u), block(64u, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
     const bool large = p.n_chunks > 0u;  // long cube list: Morton-ordered stream, chunk boxes, BVH
+    const uint32_t lds = large ? p.bvh_levels * 256u : 0u;  // the walk's per-lane stack
     switch (variant) {
     case kVariantDebug:
-        if (large) hipLaunchKernelGGL((render_kernel<true, false, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((render_kernel<true, false, false>), grid, block, 0, s, p);
+        if (large) hipLaunchKernelGGL((render_kernel<true, false, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((render_kernel<true, false, false>), grid, block, lds, s, p);
         break;
     case kVariantCount:
-        if (large) hipLaunchKernelGGL((render_kernel<false, true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, 0, s, p);
+        if (large) hipLaunchKernelGGL((render_kernel<false, true, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, lds, s, p);
         break;
     default:
         if (p.dark_materials != 0u) {
-            if (large) hipLaunchKernelGGL((render_kernel<false, false, true, true>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((render_kernel<false, false, false, true>), grid, block, 0, s, p);
+            if (large) hipLaunchKernelGGL((render_kernel<false, false, true, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((render_kernel<false, false, false, true>), grid, block, lds, s, p);
         } else {
-            if (large) hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, 0, s, p);
+            if (large) hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, lds, s, p);
         }
         break;
     }
@@ -2314,13 +2388,21 @@ int launch_heavy(const Params& p, void* stream)
     dim3 grid(kHeavyGrid, 1u, 1u), block(64u * kWgWaves, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
     const bool large = p.n_chunks > 0u;
+    const uint32_t lds = large ? kWgWaves * p.bvh_levels * 256u : 0u;
+    hipLaunchKernelGGL(heavy_gate, dim3(1u, 1u, 1u), dim3(64u, 1u, 1u), 0, s, p);
     if (p.dark_materials != 0u) {
-        if (large) hipLaunchKernelGGL((render_heavy_kernel<true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((render_heavy_kernel<false, true>), grid, block, 0, s, p);
+        if (large) hipLaunchKernelGGL((render_heavy_kernel<true, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((render_heavy_kernel<false, true>), grid, block, lds, s, p);
     } else {
-        if (large) hipLaunchKernelGGL((render_heavy_kernel<true, false>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((render_heavy_kernel<false, false>), grid, block, 0, s, p);
+        if (large) hipLaunchKernelGGL((render_heavy_kernel<true, false>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((render_heavy_kernel<false, false>), grid, block, lds, s, p);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_heavy_join(const Params& p, void* stream)
+{
+    hipLaunchKernelGGL(heavy_join, dim3(1u, 1u, 1u), dim3(64u, 1u, 1u), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 
