@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """tests/fuzz_soak.py [first_seed] [n_seeds] [max_cubes]: the fuzz of tests/test_gpu_parity.py::test_random_scenes
 over many seeds (GPU through the C-ABI against the oracle: hit planes and ray-tree hashes bit-exact, colour
-within 1 LSB on >= 99.9 % of pixels, ray counters equal).  Prints one line per failing seed and a summary."""
+within 1 LSB on >= 99.9 % of pixels, ray counters equal).  Prints one line per failing seed and a summary.
+RTX950_SOAK_HEAVY=k (read here, by the tool): also renders every scene three more times with
+rt_set_tuning(RT_TUNE_HEAVY_CLASS, k), so that the side kernel (three-wave workgroups, general cull, bundles)
+traces the tiles of cost class >= k; those frames must equal the debug variant's too."""
 import os
 import sys
 
@@ -17,6 +20,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 max_cubes = int(sys.argv[3]) if len(sys.argv) > 3 else None
 base = rt.default_scene()
 ctx = rt.Context(0)
+soak_heavy = os.environ.get("RTX950_SOAK_HEAVY")
 bad = 0
 worst = 1.0
 for seed in range(first, first + count):
@@ -29,6 +33,12 @@ for seed in range(first, first + count):
     try:
         rep = assert_parity(gfb, gpl, ofb, opl, label)
         assert (plain == gfb).all(), f"{label}: plain and debug kernels differ"
+        if soak_heavy is not None:
+            ctx.set_tuning(rt.RT_TUNE_HEAVY_CLASS, int(soak_heavy))
+            for k in range(3):
+                assert (ctx.render(f) == gfb).all(), f"{label}: side kernel (class >= {soak_heavy}), launch {k}: frame differs"
+            ctx.set_tuning(rt.RT_TUNE_HEAVY_CLASS, -1)
+            assert ctx.debug_status() == 0, f"{label}: a wait between the streams gave up"
         worst = min(worst, rep["exact_fraction"])
         assert ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict(), f"{label}: ray counters differ"
     except AssertionError as e:
