@@ -2172,7 +2172,9 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(R
 __global__ __launch_bounds__(64) void heavy_gate(const Params P)
 {
     uint32_t spins = 0u;
-    while (__hip_atomic_load(&P.queue[kHeavyGoWord], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != P.heavy_now) {
+    // ">=", wrap-safe: a launch with an empty list is not waited for by heavy_join, so the next launch's
+    // classify_tiles may have stored its own, later number before this wave looks
+    while ((int32_t)(__hip_atomic_load(&P.queue[kHeavyGoWord], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - P.heavy_now) < 0) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 24)) {
             if (threadIdx.x == 0u) P.queue[kQueueBase - 1u] = 4u;
