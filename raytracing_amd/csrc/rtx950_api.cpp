@@ -77,6 +77,7 @@ struct DeviceScratch {  // host-side view of one GPU's copy of `scratch`
 };
 static DeviceScratch g_dev_scratch[kMaxDevices];
 
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -924,11 +925,11 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     const uint32_t geom[6] = {frame->width, frame->height, frame->y0, frame->y1, n_parts, part};
     if (heavy_on && !ctx->stream_heavy) {
         // created on first use: a context that never takes this path keeps to one stream (a process has few
-        // hardware queues, and streams beyond them share).  The highest priority there is: the side kernel's few
-        // workgroups are the frame's critical path.
-        int prio_least = 0, prio_greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream_heavy, hipStreamNonBlocking, prio_greatest));
+        // hardware queues, and streams beyond them share).  Default priority on purpose: on a high-priority
+        // stream the one-wave gate, polling for a store that a kernel on a normal-priority stream has yet to
+        // make, kept that kernel from being dispatched once three contexts had side streams (priority
+        // inversion: every frame waited until the gate gave up), and it gained nothing with one or two.
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_heavy, hipStreamNonBlocking));
     }
     bool heavy_now = heavy_on && ts.heavy_list_ready && ts.heavy_list_seq == seq && std::memcmp(ts.heavy_geom, geom, sizeof(geom)) == 0 &&
                      seq + 1u != 0u;

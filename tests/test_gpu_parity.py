@@ -564,6 +564,41 @@ def test_heavy_tiles_asynchronous_entry_points(tuned_ctx, default_scene, water_s
             assert ctx.debug_status() == 0
 
 
+def test_heavy_tiles_three_contexts_in_flight(default_scene):
+    """Three contexts on one GPU, each with the side kernel on, frames interleaved without host waits: six
+    streams on four hardware queues.  The waits between a context's two streams are device-side polls; with the
+    side stream at a raised priority the polling gate starved the kernel it waited for (every frame then took
+    seconds, until the poll gave up).  Frames equal the single-context frame, no wait gives up, and the
+    sixty frames take well under a second."""
+    import time
+    import torch
+    W, H = 960, 544
+    f = default_scene.frame(W, H)
+    ctxs = [rt.Context(0) for _ in range(3)]
+    try:
+        outs = [torch.zeros((H, W), dtype=torch.int32, device="cuda") for _ in ctxs]
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.upload(default_scene)
+            c.set_tuning(rt.RT_TUNE_HEAVY_CLASS, 8)
+        want = ctxs[0].render(f)
+        for c in ctxs:
+            c.set_tuning(rt.RT_TUNE_HEAVY_CLASS, 2)
+        t0 = time.perf_counter()
+        for k in range(60):
+            ctxs[k % 3].render_device(f, outs[k % 3].data_ptr())
+        for c in ctxs:
+            c.sync()
+        dt = time.perf_counter() - t0
+        for c, o in zip(ctxs, outs):
+            assert c.debug_status() == 0
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), want)
+        assert dt < 1.0, f"60 frames over three contexts took {dt:.2f} s"
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_tuning_keys_are_validated(gpu_ctx):
     for key, bad in ((rt.RT_TUNE_HEAVY_CLASS, 9), (rt.RT_TUNE_HEAVY_CLASS, -2), (rt.RT_TUNE_HEAVY_CLASS, 2.5), (rt.RT_TUNE_COHERENT_SCALE, -1.0), (rt.RT_TUNE_SHADOW_LIST, 2), (rt.RT_TUNE_DARK_KERNEL, 0.5), (rt.RT_TUNE_FILL_MEMSET, -1), (99, 0)):
         with pytest.raises(rt.RtError) as e:
