@@ -200,6 +200,14 @@ typedef enum rt_tuning {
                                    queues).  8 = never.  Automatic: class 5 for the synchronous rt_render of
                                    frames of up to 65536 tiles, never for the asynchronous entry points.
                                    Results do not depend on it.  Next render call                            */
+    RT_TUNE_HEAVY_SYNC = 7,     /* -1 (default, automatic), 0 or 1: how the side kernel's stream and the context's stream
+                                   meet.  1: device-side - classify_tiles releases a one-wave gate kernel on the side
+                                   stream, a one-wave join kernel on the context's stream counts finished tiles
+                                   (3 us per frame).  0: events both ways (18 us per frame).  Automatic: device-side
+                                   unless a tool that runs one kernel at a time is attached to the process
+                                   (a rocprofiler-sdk tool such as rocprofv3, or HSA_TOOLS_LIB set): under such a
+                                   tool a polling kernel can wait for a kernel that is not allowed to start.
+                                   Next render call                                                          */
     RT_TUNE_BVH_DEPTH_LIMIT = 5 /* deepest BVH the per-lane walk takes (1..28, default 28 = the walk's stack);
                                    a deeper tree sends every wave through the chunk traversal.  28 levels
                                    cannot be exceeded by a real list, so tests lower it.  Next rt_scene_upload */

@@ -31,6 +31,7 @@ RT_TUNE_DARK_KERNEL = 3
 RT_TUNE_FILL_MEMSET = 4
 RT_TUNE_BVH_DEPTH_LIMIT = 5
 RT_TUNE_HEAVY_CLASS = 6
+RT_TUNE_HEAVY_SYNC = 7
 
 
 class Vec3(C.Structure):

@@ -5,6 +5,7 @@
 // function of the camera that the reference recomputes per pixel), assemble kernel parameters,
 // launch.  There is no CPU rendering path here: if HIP or the GPU is missing every call fails
 // with RT_ERR_NO_DEVICE / RT_ERR_HIP.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -85,6 +86,13 @@ struct rt_ctx {
     // `stream` meets it again in the heavy_join kernel behind its own launches (words in the queue header,
     // no events): callers see one stream, as before
     hipStream_t stream_heavy = nullptr;
+    // ... unless a tool that serialises kernels is attached to the process (rocprofv3 --pmc runs one kernel at a
+    // time and does not hand the device out in submission order: a polling kernel then waits for one that is
+    // not allowed to start, until it gives up): the two streams are then ordered by events instead, which such
+    // tools follow.  Decided when the side stream is created; RT_TUNE_HEAVY_SYNC overrides it.
+    bool heavy_events = false;
+    hipEvent_t heavy_fork = nullptr, heavy_join = nullptr;
+    int tune_heavy_sync = -1;  // -1: automatic, 0: events, 1: device-side
     std::string err;
     // scene
     bool has_scene = false;
@@ -543,6 +551,8 @@ int rt_ctx_destroy(rt_ctx* ctx)
     if (ctx->part_done) (void)hipEventDestroy(ctx->part_done);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (ctx->heavy_fork) (void)hipEventDestroy(ctx->heavy_fork);
+    if (ctx->heavy_join) (void)hipEventDestroy(ctx->heavy_join);
     if (ctx->stream_heavy) (void)hipStreamDestroy(ctx->stream_heavy);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -930,15 +940,28 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
         // make, kept that kernel from being dispatched once three contexts had side streams (priority
         // inversion: every frame waited until the gate gave up), and it gained nothing with one or two.
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_heavy, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->heavy_fork, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->heavy_join, hipEventDisableTiming));
+        // a rocprofiler-sdk tool in the process (rocprofv3, rocprof-sys) exports rocprofiler_configure; the older
+        // profilers are loaded by the HSA runtime through HSA_TOOLS_LIB
+        const char* tools = std::getenv("HSA_TOOLS_LIB");
+        ctx->heavy_events = dlsym(RTLD_DEFAULT, "rocprofiler_configure") != nullptr || (tools && *tools);
     }
+    const bool by_events = ctx->tune_heavy_sync >= 0 ? ctx->tune_heavy_sync == 0 : ctx->heavy_events;
     bool heavy_now = heavy_on && ts.heavy_list_ready && ts.heavy_list_seq == seq && std::memcmp(ts.heavy_geom, geom, sizeof(geom)) == 0 &&
                      seq + 1u != 0u;
-    // classify_tiles of this launch tells the side kernel when to start (kHeavyGoWord): no event between the streams
+    // classify_tiles of this launch tells the side kernel when to start (kHeavyGoWord): no event between the
+    // streams - unless events it must be (see rt_ctx::heavy_events): then everything enqueued on the context's
+    // stream so far comes before the side kernel, this launch's own kernels do not
+    if (heavy_now && by_events) {
+        HIP_TRY(ctx, hipEventRecord(ctx->heavy_fork, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_heavy, ctx->heavy_fork, 0));
+    }
     bool classified = false;
     if ((rc = prepare(ctx, p, ts, heavy_on, heavy_now ? seq + 1u : 0u, &classified)) != RT_OK) return rc;
     // a buffer that had to grow took the list with it (no mark can match then: the fresh marks are zero), and
     // without classify_tiles (irregular camera) nobody would say go
-    heavy_now = heavy_now && ts.heavy_list_ready && classified;
+    heavy_now = heavy_now && ts.heavy_list_ready && (classified || by_events);
     ts.heavy_list_ready = false;
     if (heavy_on) {
         p.heavy = ts.heavy;
@@ -970,10 +993,16 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     if ((rc = launch_timed(ctx, p, variant)) != RT_OK) return rc;
     if (heavy_now) {
         // after the stream's own launches, so that the host's time for these calls is not ahead of them
-        hipError_t e = (hipError_t)launch_heavy(p, (void*)ctx->stream_heavy);
+        hipError_t e = (hipError_t)launch_heavy(p, (void*)ctx->stream_heavy, !by_events);
         if (e != hipSuccess) return fail_hip(ctx, e, "heavy kernel launch");
-        e = (hipError_t)launch_heavy_join(p, (void*)ctx->stream);  // the frame is whole when the stream gets past this
-        if (e != hipSuccess) return fail_hip(ctx, e, "heavy join launch");
+        // the frame is whole when the stream gets past this
+        if (by_events) {
+            HIP_TRY(ctx, hipEventRecord(ctx->heavy_join, ctx->stream_heavy));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->heavy_join, 0));
+        } else {
+            e = (hipError_t)launch_heavy_join(p, (void*)ctx->stream);
+            if (e != hipSuccess) return fail_hip(ctx, e, "heavy join launch");
+        }
     }
     return RT_OK;
 }
@@ -1249,6 +1278,10 @@ int rt_set_tuning(rt_ctx* ctx, int key, double value)
         if (!(value >= -1.0 && value <= (double)kCostClasses && value == (double)(int)value))
             return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_HEAVY_CLASS must be -1 (automatic) or an integer in 0..8");
         ctx->tune_heavy_class = (int)value;
+        return RT_OK;
+    case RT_TUNE_HEAVY_SYNC:
+        if (!tri) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_HEAVY_SYNC must be -1 (automatic), 0 (events) or 1 (device-side)");
+        ctx->tune_heavy_sync = (int)value;
         return RT_OK;
     case RT_TUNE_BVH_DEPTH_LIMIT:
         if (!(value >= 1.0 && value <= (double)kBvhStackMax && value == (double)(uint32_t)value))

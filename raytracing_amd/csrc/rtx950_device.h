@@ -208,7 +208,8 @@ enum KernelVariant { kVariantRender = 0, kVariantDebug = 1, kVariantCount = 2 };
 int launch_queue(const Params& p, int variant, void* stream);
 int launch_render(const Params& p, int variant, void* stream, uint32_t max_workgroups);
 // launch_heavy: render_heavy_kernel for the launch's heavy list (plain frames only), on `stream`
-int launch_heavy(const Params& p, void* stream);
+// (gate: heavy_gate ahead of it, for the device-side meeting of the streams; false when events order them)
+int launch_heavy(const Params& p, void* stream, bool gate);
 // launch_heavy_join: one wave on the context's stream that ends when render_heavy_kernel has finished every
 // tile of the launch's list (a kernel behind a kernel costs the stream 2-3 us, an event wait 9)
 int launch_heavy_join(const Params& p, void* stream);

@@ -2384,14 +2384,14 @@ int launch_render(const Params& p, int variant, void* stream, uint32_t max_workg
     return (int)hipGetLastError();
 }
 
-int launch_heavy(const Params& p, void* stream)
+int launch_heavy(const Params& p, void* stream, bool gate)
 {
     if (p.grid_tx * p.grid_ty == 0u || !p.heavy) return (int)hipSuccess;
     dim3 grid(kHeavyGrid, 1u, 1u), block(64u * kWgWaves, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
     const bool large = p.n_chunks > 0u;
     const uint32_t lds = large ? kWgWaves * p.bvh_levels * 256u : 0u;
-    hipLaunchKernelGGL(heavy_gate, dim3(1u, 1u, 1u), dim3(64u, 1u, 1u), 0, s, p);
+    if (gate) hipLaunchKernelGGL(heavy_gate, dim3(1u, 1u, 1u), dim3(64u, 1u, 1u), 0, s, p);
     if (p.dark_materials != 0u) {
         if (large) hipLaunchKernelGGL((render_heavy_kernel<true, true>), grid, block, lds, s, p);
         else hipLaunchKernelGGL((render_heavy_kernel<false, true>), grid, block, lds, s, p);

@@ -510,14 +510,18 @@ def test_heavy_tiles_on_three_waves(tuned_ctx, oracle_mod, default_scene, water_
         assert (costs > 0).any()
 
 
-def test_heavy_tiles_asynchronous_entry_points(tuned_ctx, default_scene, water_scene):
+@pytest.mark.parametrize("sync", [1, 0])
+def test_heavy_tiles_asynchronous_entry_points(tuned_ctx, default_scene, water_scene, sync):
     """The side kernel behind rt_render_device / rt_render_device_part: the heavy list a launch uses was written
     by the launch before it, for that launch's camera - a moving camera, a changed frame size (the list is then
     dropped), the parts of a split, frames queued back to back into one buffer without a host wait (the side
     stream is fenced against the context's stream both ways), a debug launch in between.  Every frame equals
-    the one the same context renders with the side kernel off."""
+    the one the same context renders with the side kernel off.  Both ways of ordering the two streams
+    (RT_TUNE_HEAVY_SYNC: 1 device-side gate and join kernels, 0 events - what the library falls back to under
+    a profiler that serialises kernels)."""
     import torch
     ctx = tuned_ctx
+    ctx.set_tuning(rt.RT_TUNE_HEAVY_SYNC, sync)
     for scene in (default_scene, water_scene):
         ctx.upload(scene)
         cams = []
@@ -600,7 +604,7 @@ def test_heavy_tiles_three_contexts_in_flight(default_scene):
 
 
 def test_tuning_keys_are_validated(gpu_ctx):
-    for key, bad in ((rt.RT_TUNE_HEAVY_CLASS, 9), (rt.RT_TUNE_HEAVY_CLASS, -2), (rt.RT_TUNE_HEAVY_CLASS, 2.5), (rt.RT_TUNE_COHERENT_SCALE, -1.0), (rt.RT_TUNE_SHADOW_LIST, 2), (rt.RT_TUNE_DARK_KERNEL, 0.5), (rt.RT_TUNE_FILL_MEMSET, -1), (99, 0)):
+    for key, bad in ((rt.RT_TUNE_HEAVY_SYNC, 2), (rt.RT_TUNE_HEAVY_CLASS, 9), (rt.RT_TUNE_HEAVY_CLASS, -2), (rt.RT_TUNE_HEAVY_CLASS, 2.5), (rt.RT_TUNE_COHERENT_SCALE, -1.0), (rt.RT_TUNE_SHADOW_LIST, 2), (rt.RT_TUNE_DARK_KERNEL, 0.5), (rt.RT_TUNE_FILL_MEMSET, -1), (99, 0)):
         with pytest.raises(rt.RtError) as e:
             gpu_ctx.set_tuning(key, bad)
         assert e.value.code == rt._ffi.RT_ERR_INVALID_ARG
