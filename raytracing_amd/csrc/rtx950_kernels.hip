@@ -2,9 +2,11 @@
 //
 // Replaces (reference = ElrohirGT/Raytracing, paths relative to its root):
 //   render()            src/render.rs:234-324   -> render_kernel (one lane per pixel, 8x8 px per wave)
-//   cast_ray()          src/render.rs:73-229    -> cast_ray<PASS,DEPTH> (recursion unrolled by template
-//                                                 depth; per-level state lives in registers)
+//   cast_ray()          src/render.rs:73-229    -> trace_tree (explicit depth-first walk, one copy of the node
+//                                                 code, per-lane frames of waiting nodes in LDS) + light_term
 //   cast_shadow()       src/render.rs:44-70     -> shadow_query (inlined, list order, early exit)
+//   the slowest tiles of a frame                -> render_heavy_kernel (three waves per tile on a second stream:
+//                                                 same functions, same arithmetic; see "heavy tiles")
 //   Cube::ray_intersect src/cube.rs:77-218      -> cull_test (one conservative test per cube for all 64
 //                                                 rays of a wave) + cube_slab_approx (per-ray two-sided
 //                                                 filter, FMA) + cube_exact (IEEE, only where needed)
