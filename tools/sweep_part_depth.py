@@ -1,6 +1,6 @@
 """What one rank of an N-GPU job can do by itself (no collective): its part of the 4K frame rendered
 back-to-back with 1, 2 or 3 frames in flight.  Prints ms per frame, slowest part of each N.
-Usage: python tools/sweep_part_depth.py [workload] [grid limit with frames in flight, 0 = library default]"""
+Usage: python tools/sweep_part_depth.py [workload] [grid limit with frames in flight, 0 = library default] [comm|-] [RT_TUNE_HEAVY_CLASS]"""
 import os
 import sys
 import time
@@ -18,8 +18,10 @@ scene = bench.make_scene(rt, kind, kwargs)
 frame = scene.frame(W, H)
 dev = torch.device("cuda", 0)
 ctxs = [rt.Context(0) for _ in range(4)]
+heavy = int(sys.argv[4]) if len(sys.argv) > 4 else -1
 for c in ctxs:
     c.upload(scene)
+    c.set_tuning(rt.RT_TUNE_HEAVY_CLASS, heavy)
 bufs = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in ctxs]
 torch.cuda.synchronize()
 frames = 200
@@ -52,4 +54,4 @@ for n in (1, 2, 4, 8):
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) / frames * 1e3
             worst = max(worst, ms)
-        print(f"{workload} grid_limit={limit if depth > 1 else 0} N={n} frames_in_flight={depth}: slowest part {worst:.4f} ms/frame", flush=True)
+        print(f"{workload} grid_limit={limit if depth > 1 else 0} heavy_class={heavy} N={n} frames_in_flight={depth}: slowest part {worst:.4f} ms/frame", flush=True)
