@@ -939,9 +939,10 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
         // stream the one-wave gate, polling for a store that a kernel on a normal-priority stream has yet to
         // make, kept that kernel from being dispatched once three contexts had side streams (priority
         // inversion: every frame waited until the gate gave up), and it gained nothing with one or two.
+        // (the events first: the stream's existence is what says that all three are there)
+        if (!ctx->heavy_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->heavy_fork, hipEventDisableTiming));
+        if (!ctx->heavy_join) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->heavy_join, hipEventDisableTiming));
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_heavy, hipStreamNonBlocking));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->heavy_fork, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->heavy_join, hipEventDisableTiming));
         // a rocprofiler-sdk tool in the process (rocprofv3, rocprof-sys) exports rocprofiler_configure; the older
         // profilers are loaded by the HSA runtime through HSA_TOOLS_LIB
         const char* tools = std::getenv("HSA_TOOLS_LIB");
