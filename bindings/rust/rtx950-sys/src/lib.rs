@@ -16,6 +16,7 @@ pub const RT_TUNE_FILL_MEMSET: c_int = 4;
 pub const RT_TUNE_BVH_DEPTH_LIMIT: c_int = 5;
 pub const RT_TUNE_HEAVY_CLASS: c_int = 6;
 pub const RT_TUNE_HEAVY_SYNC: c_int = 7;
+pub const RT_TUNE_HEAVY_SPIN_LIMIT: c_int = 8;
 pub const RT_MAX_DEPTH: u32 = 3; // src/render.rs:83
 pub const RT_MAX_LIGHTS: u32 = 16;
 pub const RT_TEXTURE_NONE: i32 = -1; // `texture: None`, src/material.rs:6
@@ -28,6 +29,7 @@ pub const RT_ERR_HIP: c_int = -3;
 pub const RT_ERR_NO_SCENE: c_int = -4;
 pub const RT_ERR_UNSUPPORTED: c_int = -5;
 pub const RT_ERR_LIMIT: c_int = -6;
+pub const RT_ERR_DEVICE_WAIT: c_int = -7;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default, PartialEq)]

@@ -20,8 +20,9 @@
  *     (reference `render` needs `&mut Framebuffer`, so it is not re-entrant either).
  *   - every call makes its context's GPU current for the duration of the call and restores the calling
  *     thread's current HIP device before it returns.
- *   - the library reads no environment variables; test and tuning knobs are explicit calls (rt_set_tuning,
- *     rt_set_grid_limit).
+ *   - test and tuning knobs are explicit calls (rt_set_tuning, rt_set_grid_limit).  The library reads ONE
+ *     environment variable, HSA_TOOLS_LIB, and only to see whether a profiler that serialises kernels is attached
+ *     (see RT_TUNE_HEAVY_SYNC, which overrides what it concludes: set it explicitly when profiling the side kernel).
  */
 #ifndef RTX950_H
 #define RTX950_H
@@ -42,7 +43,9 @@ typedef enum rt_status {
     RT_ERR_HIP = -3,           /* a HIP call failed; message carries hipGetErrorString       */
     RT_ERR_NO_SCENE = -4,      /* rt_render* called before rt_scene_upload                   */
     RT_ERR_UNSUPPORTED = -5,   /* e.g. max_depth > 3, more lights than RT_MAX_LIGHTS         */
-    RT_ERR_LIMIT = -6          /* a fixed-capacity entry point was given too large an input  */
+    RT_ERR_LIMIT = -6,         /* a fixed-capacity entry point was given too large an input  */
+    RT_ERR_DEVICE_WAIT = -7    /* rt_sync: a device-side wait between the context's two streams (side kernel for
+                                  heavy tiles) gave up; frames rendered since the last rt_sync may be incomplete */
 } rt_status;
 
 /* reference src/render.rs:83 — `if depth > 3 { return sky }` */
@@ -208,6 +211,12 @@ typedef enum rt_tuning {
                                    (a rocprofiler-sdk tool such as rocprofv3, or HSA_TOOLS_LIB set): under such a
                                    tool a polling kernel can wait for a kernel that is not allowed to start.
                                    Next render call                                                          */
+    RT_TUNE_HEAVY_SPIN_LIMIT = 8, /* polls the join kernel of the side stream makes before it gives up: 0 = the default
+                                   (2^24, seconds), 1 = none at all: every launch with a side kernel is REPORTED as
+                                   given up (fault injection for the test of the recovery path: rt_render renders
+                                   the frame again without the side kernel and disables it for the context, rt_sync
+                                   returns RT_ERR_DEVICE_WAIT).  Setting 0 puts a disabled side kernel back in
+                                   service.  Next render call                                                 */
     RT_TUNE_BVH_DEPTH_LIMIT = 5 /* deepest BVH the per-lane walk takes (1..28, default 28 = the walk's stack);
                                    a deeper tree sends every wave through the chunk traversal.  28 levels
                                    cannot be exceeded by a real list, so tests lower it.  Next rt_scene_upload */
@@ -323,7 +332,10 @@ int rt_gather_bands(rt_ctx* const* ctxs, uint32_t n_ctx, const uint32_t* const* 
                     uint32_t* d_band_on_ctx0, uint64_t* out_bytes_moved);
 
 /* Wait for all work enqueued on the context's stream.  No reference counterpart (the reference
- * is synchronous). */
+ * is synchronous).  Returns RT_ERR_DEVICE_WAIT if a launch since the last rt_sync used the side kernel for heavy
+ * tiles (RT_TUNE_HEAVY_CLASS) and one of its device-side waits gave up: those frames may be incomplete and must be
+ * rendered again; the side kernel is then out of service for the context (RT_TUNE_HEAVY_SPIN_LIMIT 0 restores it).
+ * The synchronous rt_render handles that case itself: it renders the frame again without the side kernel. */
 int rt_sync(rt_ctx* ctx);
 
 /* Run the counting variant of the render kernel on the band (no image output) and return the
@@ -369,9 +381,9 @@ int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t*
  * render_heavy_kernel<long list, dark-material test> runs beside it.  No reference counterpart. */
 const char* rt_kernel_name(const rt_ctx* ctx);
 
-/* Diagnostic, no counterpart in the reference: 0 unless a wave of a heavy tile's workgroup (RT_TUNE_HEAVY_CLASS)
- * gave up waiting for its partners in one of the context's launches (never expected; the frame is then
- * wrong).  Waits for the stream. */
+/* Diagnostic, no counterpart in the reference: 0 unless a device-side wait of the side kernel for heavy tiles
+ * (RT_TUNE_HEAVY_CLASS) gave up in one of the context's launches and neither rt_render nor rt_sync has dealt
+ * with it yet (never expected; see rt_sync).  Waits for the stream. */
 int rt_debug_status(rt_ctx* ctx, uint32_t* out_word);
 
 /* Diagnostic, no counterpart in the reference: cycles each 8x8 tile of the context's last launch took

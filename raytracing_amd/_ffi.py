@@ -19,6 +19,7 @@ RT_ERR_HIP = -3
 RT_ERR_NO_SCENE = -4
 RT_ERR_UNSUPPORTED = -5
 RT_ERR_LIMIT = -6
+RT_ERR_DEVICE_WAIT = -7
 RT_MAX_DEPTH = 3
 RT_MAX_LIGHTS = 16
 RT_TEXTURE_NONE = -1
@@ -32,6 +33,7 @@ RT_TUNE_FILL_MEMSET = 4
 RT_TUNE_BVH_DEPTH_LIMIT = 5
 RT_TUNE_HEAVY_CLASS = 6
 RT_TUNE_HEAVY_SYNC = 7
+RT_TUNE_HEAVY_SPIN_LIMIT = 8
 
 
 class Vec3(C.Structure):

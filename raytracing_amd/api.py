@@ -233,7 +233,8 @@ class Context:
 
     # the library's defaults; a test session may override entries (tests/conftest.py) to soak a path
     DEFAULT_TUNING = {_ffi.RT_TUNE_COHERENT_SCALE: 1.0, _ffi.RT_TUNE_SHADOW_LIST: -1, _ffi.RT_TUNE_DARK_KERNEL: -1,
-                      _ffi.RT_TUNE_FILL_MEMSET: 0, _ffi.RT_TUNE_BVH_DEPTH_LIMIT: 28, _ffi.RT_TUNE_HEAVY_CLASS: -1, _ffi.RT_TUNE_HEAVY_SYNC: -1}
+                      _ffi.RT_TUNE_FILL_MEMSET: 0, _ffi.RT_TUNE_BVH_DEPTH_LIMIT: 28, _ffi.RT_TUNE_HEAVY_CLASS: -1, _ffi.RT_TUNE_HEAVY_SYNC: -1,
+                      _ffi.RT_TUNE_HEAVY_SPIN_LIMIT: 0}
 
     def reset_tuning(self):
         for key, value in self.DEFAULT_TUNING.items():
@@ -263,6 +264,10 @@ class Context:
         a, b = C.c_uint32(), C.c_uint32()
         self._check(self._lib.rt_frame_row_extent(self._ctx, C.byref(frame), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_error(self) -> str:
+        """rt_last_error of this context (also set, as a warning, by a call that recovered by itself)."""
+        return (self._lib.rt_last_error(self._ctx) or b"").decode()
 
     def debug_status(self) -> int:
         """rt_debug_status: 0 unless a heavy tile's workgroup gave up waiting (never expected)."""

@@ -93,6 +93,14 @@ struct rt_ctx {
     bool heavy_events = false;
     hipEvent_t heavy_fork = nullptr, heavy_join = nullptr;
     int tune_heavy_sync = -1;  // -1: automatic, 0: events, 1: device-side
+    uint32_t tune_heavy_spin = 0;  // heavy_join's patience in polls (0: the default, 1: none - the recovery path's test)
+    // A device-side wait of the side kernel's machinery that gave up leaves a status word in the queue header and,
+    // possibly, an incomplete frame.  Every launch with a side kernel sets heavy_unchecked; the next host wait on
+    // the context (rt_render's, rt_sync's) reads the word back and, if it is set, takes the side kernel out of
+    // service for the context (heavy_disabled) - rt_render then renders the frame again without it.
+    bool heavy_unchecked = false;
+    bool heavy_disabled = false;
+    uint32_t* h_status = nullptr;  // one pinned word: the read-back target
     std::string err;
     // scene
     bool has_scene = false;
@@ -475,6 +483,43 @@ int launch_timed(rt_ctx* ctx, const Params& p, int variant)
     return RT_OK;
 }
 
+
+// The host has just waited for the context's stream.  If a launch since the last check used the side kernel, read
+// the status word of the queue header back; non-zero = one of the device-side waits between the two streams (or
+// inside a heavy tile's workgroup) gave up, and the frames rendered since the last check may be incomplete.  The
+// side kernel is then taken out of service for this context, its stream drained, the word cleared.  Returns the
+// word (0: all is well) through *out_word.
+int check_heavy_status(rt_ctx* ctx, uint32_t* out_word)
+{
+    *out_word = 0u;
+    if (!ctx->heavy_unchecked) return RT_OK;
+    ctx->heavy_unchecked = false;
+    if (!ctx->own.queue) return RT_OK;
+    *ctx->h_status = 0u;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->own.queue + kQueueBase - 1u, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t word = *ctx->h_status;
+    if (word == 0u) return RT_OK;
+    ctx->heavy_disabled = true;
+    ctx->own.heavy_list_ready = false;
+    if (ctx->stream_heavy) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_heavy));  // whatever of the side kernel is still running
+    HIP_TRY(ctx, hipMemsetAsync(ctx->own.queue + kQueueBase - 1u, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out_word = word;
+    return RT_OK;
+}
+
+const char* heavy_wait_name(uint32_t word)
+{
+    switch (word) {
+    case 1u: return "a tracer wave's wait for its shader waves";
+    case 2u: return "a shader wave's wait for its tracer";
+    case 3u: return "the join of the side kernel with the context's stream";
+    case 4u: return "the side kernel's start gate";
+    default: return "a device-side wait";
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -499,6 +544,10 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
         return fail_hip(nullptr, e, "hipStreamCreateWithFlags");
     }
     e = hipMalloc((void**)&c->d_counters, kCounterBytes);
+    if (e == hipSuccess) {
+        e = hipHostMalloc((void**)&c->h_status, 64, hipHostMallocDefault);
+        if (e != hipSuccess) (void)hipFree(c->d_counters);
+    }
     if (e != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
@@ -514,6 +563,7 @@ int rt_ctx_create(int device, rt_ctx** out_ctx)
             e = hipGetSymbolAddress((void**)&base, HIP_SYMBOL(scratch));
             if (e != hipSuccess || !base) {
                 (void)hipFree(c->d_counters);
+                (void)hipHostFree(c->h_status);
                 (void)hipStreamDestroy(c->stream);
                 delete c;
                 return fail_hip(nullptr, e, "hipGetSymbolAddress(scratch)");
@@ -542,6 +592,7 @@ int rt_ctx_destroy(rt_ctx* ctx)
     (void)hipFree(ctx->d_fb);
     for (auto& b : ctx->d_dbg) (void)hipFree(b);
     (void)hipFree(ctx->d_counters);
+    (void)hipHostFree(ctx->h_status);
     (void)hipFree(ctx->own.stamps);
     (void)hipFree(ctx->own.queue);
     (void)hipFree(ctx->own.cost);
@@ -930,7 +981,7 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     const size_t launch_tiles = (size_t)((frame->width + 7u) / 8u) * ((rt_part_rows(frame->y1 - frame->y0, n_parts, part) + 7u) / 8u);
     const uint32_t heavy_class = ctx->tune_heavy_class >= 0 ? (uint32_t)ctx->tune_heavy_class
                                  : ((synchronous && launch_tiles <= kAutoHeavyMaxTiles && ctx->base.n_chunks == 0u) ? kDefaultHeavyClass : kCostClasses);
-    const bool heavy_on = variant == kVariantRender && paints && heavy_class < kCostClasses;
+    const bool heavy_on = variant == kVariantRender && paints && heavy_class < kCostClasses && !ctx->heavy_disabled;
     const uint32_t seq = ts.launch_seq;  // this launch's; prepare() increments it
     const uint32_t geom[6] = {frame->width, frame->height, frame->y0, frame->y1, n_parts, part};
     if (heavy_on && !ctx->stream_heavy) {
@@ -969,6 +1020,7 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
         p.heavy_mark = ts.heavy_mark;
         p.heavy_class = heavy_class;
         p.split_thr = ctx->base.split_thr;
+        p.heavy_spin_limit = ctx->tune_heavy_spin;
         p.heavy_now = heavy_now ? seq + 1u : 0u;
         p.heavy_next = (seq + 2u != 0u) ? seq + 2u : 0u;
         if (p.heavy_next != 0u) {
@@ -993,6 +1045,7 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     }
     if ((rc = launch_timed(ctx, p, variant)) != RT_OK) return rc;
     if (heavy_now) {
+        ctx->heavy_unchecked = true;
         // after the stream's own launches, so that the host's time for these calls is not ahead of them
         hipError_t e = (hipError_t)launch_heavy(p, (void*)ctx->stream_heavy, !by_events);
         if (e != hipSuccess) return fail_hip(ctx, e, "heavy kernel launch");
@@ -1030,13 +1083,23 @@ int rt_render(rt_ctx* ctx, const rt_frame* frame, uint32_t* out_0rgb, const rt_d
         dev.hit_sphere = host_planes[1] ? ctx->d_dbg[1] : nullptr;
         dev.tree_hash = host_planes[2] ? ctx->d_dbg[2] : nullptr;
     }
-    if ((rc = render_part(ctx, frame, 1u, 0u, ctx->d_fb, &dev, true)) != RT_OK) return rc;
-    // the single read-back
-    HIP_TRY(ctx, hipMemcpyAsync(out_0rgb, ctx->d_fb, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    for (int k = 0; k < 3; ++k)
-        if (host_planes[k])
-            HIP_TRY(ctx, hipMemcpyAsync(host_planes[k], ctx->d_dbg[k], npx * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = render_part(ctx, frame, 1u, 0u, ctx->d_fb, &dev, true)) != RT_OK) return rc;
+        // the single read-back
+        HIP_TRY(ctx, hipMemcpyAsync(out_0rgb, ctx->d_fb, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        for (int k = 0; k < 3; ++k)
+            if (host_planes[k])
+                HIP_TRY(ctx, hipMemcpyAsync(host_planes[k], ctx->d_dbg[k], npx * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // A frame that a device-side wait of the side kernel gave up on is never handed out: the side kernel is out
+        // of service for this context from here on, and the frame is rendered again without it (once: the second
+        // pass has no side kernel to wait for).  rt_last_error keeps the reason although the call succeeds.
+        uint32_t word = 0u;
+        if ((rc = check_heavy_status(ctx, &word)) != RT_OK) return rc;
+        if (word == 0u) break;
+        (void)fail(ctx, RT_OK, std::string("rt_render: ") + heavy_wait_name(word) + " gave up (status " + std::to_string(word) +
+                                   "); the side kernel for heavy tiles is disabled for this context and the frame was rendered again without it");
+    }
     return RT_OK;
 }
 
@@ -1045,6 +1108,13 @@ int rt_sync(rt_ctx* ctx)
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
     ENTER_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t word = 0u;
+    int rc = check_heavy_status(ctx, &word);
+    if (rc != RT_OK) return rc;
+    if (word != 0u)
+        return fail(ctx, RT_ERR_DEVICE_WAIT, std::string("rt_sync: ") + heavy_wait_name(word) + " gave up (status " + std::to_string(word) +
+                                                 "): frames rendered with the side kernel since the last rt_sync may be incomplete - render them again; "
+                                                 "the side kernel for heavy tiles is disabled for this context from here on");
     return RT_OK;
 }
 
@@ -1283,6 +1353,12 @@ int rt_set_tuning(rt_ctx* ctx, int key, double value)
     case RT_TUNE_HEAVY_SYNC:
         if (!tri) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_HEAVY_SYNC must be -1 (automatic), 0 (events) or 1 (device-side)");
         ctx->tune_heavy_sync = (int)value;
+        return RT_OK;
+    case RT_TUNE_HEAVY_SPIN_LIMIT:
+        if (!(value >= 0.0 && value <= 4294967295.0 && value == (double)(uint32_t)value))
+            return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_HEAVY_SPIN_LIMIT must be an integer in 0..2^32-1 (0: default)");
+        ctx->tune_heavy_spin = (uint32_t)value;
+        if (value == 0.0) ctx->heavy_disabled = false;  // the default restores a side kernel that a give-up took out of service
         return RT_OK;
     case RT_TUNE_BVH_DEPTH_LIMIT:
         if (!(value >= 1.0 && value <= (double)kBvhStackMax && value == (double)(uint32_t)value))

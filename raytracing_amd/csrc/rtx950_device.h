@@ -166,12 +166,14 @@ struct Params {
     // flight: 1.23 -> 0.94 ms)
     uint32_t bvh_levels;
     float split_thr;  // heavy tiles: a wave whose cull inflation exceeds this is walked bundle by bundle (cube_query, SPLIT)
+    uint32_t heavy_spin_limit;  // heavy_join: polls before it gives up (0: 2^24; 1: report at once, RT_TUNE_HEAVY_SPIN_LIMIT)
 };
 constexpr uint32_t kHeavyCap = 1024;       // heavy tiles per launch; the rest stay with render_kernel
 constexpr uint32_t kHeavyTarget = 512;     // classify_tiles raises the class threshold until about this many tiles qualify:
                                            // what the side kernel's three-wave workgroups can hold at once beside render_kernel
 constexpr uint32_t kHeavyCountWord = 9;    // word of a queue header bank that counts the heavy list's entries
 constexpr uint32_t kHeavyDoneWord = 10;    // ... and the one that counts the entries render_heavy_kernel has finished
+constexpr uint32_t kHeavyExitWord = 11;    // ... and the one that counts the workgroups of render_heavy_kernel that have ended
 constexpr uint32_t kHeavyGoWord = 48;      // queue header word (a cache line of its own): classify_tiles stores the launch's heavy_now
                                            // here, render_heavy_kernel starts its tiles when it reads it
 constexpr uint32_t kHeavyClassWord = 62;   // queue header word: the lowest class that fits (classify_tiles -> build_queue)

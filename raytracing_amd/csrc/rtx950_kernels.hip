@@ -2135,9 +2135,16 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(R
     const uint32_t* list = P.heavy + P.qsel * kHeavyCap;
     uint32_t items = 0u;
     for (uint32_t item = blockIdx.x; item < n_heavy; item += gridDim.x) {
+        // an entry outside the launch's tile grid cannot come from this launch's list (a gate that gave up lets
+        // the kernel start before the list is whole): skipped by every wave alike, and counted as finished
+        const uint32_t raw = list[item];
+        if ((raw & 0x7FFFu) >= P.grid_tx || (raw >> 16) >= P.grid_ty) {
+            if (threadIdx.x == 0u) __hip_atomic_fetch_add(&P.queue[P.qsel * 16u + kHeavyDoneWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         ++items;
         if (wave == 0u) {
-            const uint32_t entry = list[item] & ~kEntryNoCubes;
+            const uint32_t entry = raw & ~kEntryNoCubes;
 #ifdef RTX_PROFILE
             const uint32_t prof_c0 = (uint32_t)__builtin_readcyclecounter();
             if (threadIdx.x == 0u) { ctl.prof_wait = 0u; for (uint32_t w = 0; w < kShaders; ++w) { ctl.prof_busy[w] = 0u; ctl.prof_nodes[w] = 0u; } }
@@ -2161,6 +2168,12 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(R
         }
     }
     if (threadIdx.x == 0u && ctl.error != 0u) P.queue[kQueueBase - 1u] = ctl.error;  // header word 63: rt_debug_status
+    // This workgroup is done with the launch's header bank and list (it read the count when it started): heavy_join
+    // waits for every workgroup's mark, not only for the tiles, because the launch after next reuses the bank - a
+    // workgroup that started late would otherwise read that launch's count and trace its tiles with this launch's
+    // camera (an empty list ends the join at once, and the side kernel shares hardware queues with other streams).
+    __syncthreads();
+    if (threadIdx.x == 0u) __hip_atomic_fetch_add(&P.queue[P.qsel * 16u + kHeavyExitWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // heavy_gate: the side stream waits here, one wave, until classify_tiles of the same launch says go
@@ -2193,14 +2206,18 @@ __global__ __launch_bounds__(64) void heavy_join(const Params P)
 {
     const uint32_t listed = __hip_atomic_load(&P.queue[P.qsel * 16u + kHeavyCountWord], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t want = listed < kHeavyCap ? listed : kHeavyCap;
+    const uint32_t limit = P.heavy_spin_limit ? P.heavy_spin_limit : (1u << 24);
+    // heavy_spin_limit == 1 (RT_TUNE_HEAVY_SPIN_LIMIT, the recovery path's test): no patience at all - a launch
+    // with a side kernel is reported as given up without a look at the counts
+    bool gave_up = (P.heavy_spin_limit == 1u);
     uint32_t spins = 0u;
-    while (__hip_atomic_load(&P.queue[P.qsel * 16u + kHeavyDoneWord], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    // every listed tile finished AND every workgroup of render_heavy_kernel gone (see the kernel's last lines)
+    while (!gave_up && (__hip_atomic_load(&P.queue[P.qsel * 16u + kHeavyDoneWord], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want ||
+                        __hip_atomic_load(&P.queue[P.qsel * 16u + kHeavyExitWord], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < kHeavyGrid)) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 24)) {
-            if (threadIdx.x == 0u) P.queue[kQueueBase - 1u] = 3u;
-            break;
-        }
+        if (++spins > limit) gave_up = true;
     }
+    if (gave_up && threadIdx.x == 0u) P.queue[kQueueBase - 1u] = 3u;
 }
 
 // ---------------------------------------------------------------- classify_tiles
