@@ -17,6 +17,8 @@ pub const RT_TUNE_BVH_DEPTH_LIMIT: c_int = 5;
 pub const RT_TUNE_HEAVY_CLASS: c_int = 6;
 pub const RT_TUNE_HEAVY_SYNC: c_int = 7;
 pub const RT_TUNE_HEAVY_SPIN_LIMIT: c_int = 8;
+pub const RT_TUNE_WAVEFRONT: c_int = 9;
+pub const RT_TUNE_WAVEFRONT_CAP: c_int = 10;
 pub const RT_MAX_DEPTH: u32 = 3; // src/render.rs:83
 pub const RT_MAX_LIGHTS: u32 = 16;
 pub const RT_TEXTURE_NONE: i32 = -1; // `texture: None`, src/material.rs:6
@@ -191,6 +193,7 @@ extern "C" {
     pub fn rt_enable_timing(ctx: *mut rt_ctx, enable: c_int) -> c_int;
     pub fn rt_set_grid_limit(ctx: *mut rt_ctx, max_workgroups: u32) -> c_int;
     pub fn rt_selftest_division(ctx: *mut rt_ctx, seed: u32, n_cases: u64, out_mismatches: *mut u64, out_cases: *mut u64) -> c_int;
+    pub fn rt_debug_wavefront_items(ctx: *mut rt_ctx, level: u32, out_words: *mut u32, cap_items: usize, out_items: *mut usize) -> c_int;
     pub fn rt_get_stream(ctx: *mut rt_ctx, out_hip_stream: *mut *mut c_void) -> c_int;
     pub fn rt_count_executed(ctx: *mut rt_ctx, frame: *const rt_frame, n_parts: u32, part: u32, out: *mut rt_counters, exec: *mut rt_exec_counters) -> c_int;
     pub fn rt_set_tuning(ctx: *mut rt_ctx, key: c_int, value: f64) -> c_int;

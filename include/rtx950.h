@@ -217,6 +217,12 @@ typedef enum rt_tuning {
                                    the frame again without the side kernel and disables it for the context, rt_sync
                                    returns RT_ERR_DEVICE_WAIT).  Setting 0 puts a disabled side kernel back in
                                    service.  Next render call                                                 */
+    RT_TUNE_WAVEFRONT = 9,      /* -1 (default, automatic), 0 or 1: plain frames are rendered by the wavefront launches - one
+                                   per ray-tree level over bundles of coherent rays, then a combine launch - instead of
+                                   the tile-resident walk of the whole tree.  Results do not depend on it.  Next render call */
+    RT_TUNE_WAVEFRONT_CAP = 10, /* items (ray bundles) per deeper level that the wavefront buffers hold; 0 (default) = from
+                                   the frame size.  Tiles whose bundles do not fit are rendered by the tile-resident
+                                   kernel instead, so tests lower it to force that path.  Next render call            */
     RT_TUNE_BVH_DEPTH_LIMIT = 5 /* deepest BVH the per-lane walk takes (1..28, default 28 = the walk's stack);
                                    a deeper tree sends every wave through the chunk traversal.  28 levels
                                    cannot be exceeded by a real list, so tests lower it.  Next rt_scene_upload */
@@ -391,6 +397,12 @@ int rt_debug_status(rt_ctx* ctx, uint32_t* out_word);
  * part); the library uses them only to order the next launch's queue.  Copies min(cap, tiles) words after
  * waiting for the stream; *out_tiles = tiles of the last launch's grid buffer. */
 int rt_debug_tile_costs(rt_ctx* ctx, uint32_t* out, size_t cap, size_t* out_tiles);
+
+/* Diagnostic, no counterpart in the reference: the item records (ray bundles, 8 words each: cycles the item took,
+ * kind | pass << 1, lane mask low / high, root tile entry, first child, children, launch stamp) that the context's last
+ * wavefront frame (RT_TUNE_WAVEFRONT) allocated at ray-tree level `level` (1..3; 0: the root slots, two per tile
+ * position).  Copies min(cap_items, items) records after waiting for the stream; *out_items = items allocated. */
+int rt_debug_wavefront_items(rt_ctx* ctx, uint32_t level, uint32_t* out_words, size_t cap_items, size_t* out_items);
 
 /* Raw HIP stream of the context as an opaque pointer (hipStream_t), for hosts that order their
  * own work (e.g. an RCCL gather) after the render.  No reference counterpart. */

@@ -34,6 +34,8 @@ RT_TUNE_BVH_DEPTH_LIMIT = 5
 RT_TUNE_HEAVY_CLASS = 6
 RT_TUNE_HEAVY_SYNC = 7
 RT_TUNE_HEAVY_SPIN_LIMIT = 8
+RT_TUNE_WAVEFRONT = 9
+RT_TUNE_WAVEFRONT_CAP = 10
 
 
 class Vec3(C.Structure):
@@ -164,6 +166,7 @@ ABI_SYMBOLS = {
     "rt_kernel_name": (C.c_char_p, [C.c_void_p]),
     "rt_debug_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rt_debug_tile_costs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rt_debug_wavefront_items": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "rt_host_free": (C.c_int, [C.c_void_p]),
     "rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_void_p]),

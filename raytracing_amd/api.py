@@ -234,7 +234,7 @@ class Context:
     # the library's defaults; a test session may override entries (tests/conftest.py) to soak a path
     DEFAULT_TUNING = {_ffi.RT_TUNE_COHERENT_SCALE: 1.0, _ffi.RT_TUNE_SHADOW_LIST: -1, _ffi.RT_TUNE_DARK_KERNEL: -1,
                       _ffi.RT_TUNE_FILL_MEMSET: 0, _ffi.RT_TUNE_BVH_DEPTH_LIMIT: 28, _ffi.RT_TUNE_HEAVY_CLASS: -1, _ffi.RT_TUNE_HEAVY_SYNC: -1,
-                      _ffi.RT_TUNE_HEAVY_SPIN_LIMIT: 0}
+                      _ffi.RT_TUNE_HEAVY_SPIN_LIMIT: 0, _ffi.RT_TUNE_WAVEFRONT: -1, _ffi.RT_TUNE_WAVEFRONT_CAP: 0}
 
     def reset_tuning(self):
         for key, value in self.DEFAULT_TUNING.items():
@@ -281,6 +281,15 @@ class Context:
         self._check(self._lib.rt_debug_tile_costs(self._ctx, None, 0, C.byref(n)))
         out = np.zeros(n.value, dtype=np.uint32)
         self._check(self._lib.rt_debug_tile_costs(self._ctx, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
+        return out
+
+    def wavefront_items(self, level):
+        """rt_debug_wavefront_items: uint32 [items, 8] records of the last wavefront frame at `level`."""
+        n = C.c_size_t()
+        self._check(self._lib.rt_debug_wavefront_items(self._ctx, level, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 8), dtype=np.uint32)
+        if n.value:
+            self._check(self._lib.rt_debug_wavefront_items(self._ctx, level, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
         return out
 
     def kernel_name(self) -> str:

@@ -60,6 +60,17 @@ struct TileScratch {
     uint32_t heavy_geom[6] = {0, 0, 0, 0, 0, 0};  // width, height, y0, y1, n_parts, part
 };
 
+// Work buffers of the wavefront path (WfParams): one allocation per context, sized by the launch's tile grid.
+struct WfScratch {
+    char* base = nullptr;
+    size_t bytes = 0;
+    size_t tiles = 0;            // tile grid the buffers were sized for
+    uint32_t cap_tune = 0;       // RT_TUNE_WAVEFRONT_CAP the buffers were sized with
+    uint32_t seq = 0;            // stamp of the last launch
+    WfParams w{};                // pointers and capacities (seq, level set per launch)
+    size_t zero_bytes = 0;       // leading part that must start at zero: header, pending, redo marks, item records
+};
+
 // ---- the allocation-free entry point's work buffers (rt_render_device_noalloc) -------------------------
 // One array per GPU, held until the process ends: queue (64 + 9 x tiles words), stamps (64 + tiles + coarse
 // words) and tile costs (tiles + 1 words) for frames of up to RT_NOALLOC_MAX_TILES 8x8 tiles (5.8 MB).
@@ -133,6 +144,10 @@ struct rt_ctx {
     size_t dbg_capacity[3] = {0, 0, 0};
     unsigned long long* d_counters = nullptr;
     TileScratch own;  // tile stamps, work queue, tile costs of this context's launches
+    WfScratch wf;     // item, node and ray buffers of the wavefront path
+    int tune_wavefront = -1;      // -1: automatic, 0: never, 1: every plain frame
+    uint32_t tune_wf_cap = 0;     // items per deeper level (0: from the tile grid)
+    bool scene_has_children = false;  // some material reflects or refracts: the ray tree can be deeper than its root
     // rt_render_multi: this context's compact part of the frame, and the event that says it has reached GPU0
     uint32_t* d_part = nullptr;
     size_t part_capacity = 0;  // in pixels
@@ -381,7 +396,8 @@ int grow(rt_ctx* ctx, TileScratch& ts, uint32_t** buf, size_t* cap, size_t need,
     return RT_OK;
 }
 
-int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint32_t heavy_go = 0u, bool* out_classified = nullptr)
+int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint32_t heavy_go = 0u, bool* out_classified = nullptr,
+            uint32_t* wf_header = nullptr)
 {
     if (out_classified) *out_classified = false;
     p.tile_stamps = nullptr;
@@ -424,6 +440,7 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint
     TileParams t;
     if (!projection_setup(p, t)) {
         HIP_TRY(ctx, hipMemsetAsync(ts.queue + (p.qsel ^ 1u) * 16u, 0, 16 * sizeof(uint32_t), ctx->stream));
+        if (wf_header) HIP_TRY(ctx, hipMemsetAsync(wf_header, 0, (kWfRedoBase + 16u) * sizeof(uint32_t), ctx->stream));  // what classify_tiles would have zeroed
         return RT_OK;
     }
     t.cube_filt = p.cube_filt;
@@ -433,6 +450,7 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint
     t.qsel = p.qsel;
     t.heavy_on = heavy_on ? 1u : 0u;
     t.heavy_go = heavy_go;
+    t.wf_header = wf_header;
     if (++ts.frame_id == 0u) {  // wrapped: stale stamps could alias, start over
         HIP_TRY(ctx, hipMemsetAsync(ts.stamps, 0, ts.stamps_cap * sizeof(uint32_t), ctx->stream));
         ts.frame_id = 1u;
@@ -483,6 +501,101 @@ int launch_timed(rt_ctx* ctx, const Params& p, int variant)
     return RT_OK;
 }
 
+
+// Buffers of the wavefront path for a launch of n_tiles tiles.  Level 0 has two items (passes) per tile; a deeper
+// level holds up to twice the tile count (every tile's rays in two bundles), within [4096, 2^19] - a launch whose
+// items do not fit hands the tiles concerned to render_kernel (redo list), so the capacity bounds memory, not
+// correctness.  4K: 1.75 GB, 8K: 3.9 GB per context, next to 288 GB.
+int ensure_wavefront(rt_ctx* ctx, size_t n_tiles)
+{
+    WfScratch& f = ctx->wf;
+    if (f.base && f.tiles >= n_tiles && f.cap_tune == ctx->tune_wf_cap) return RT_OK;
+    if (f.base) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(f.base));
+    }
+    f = WfScratch{};
+    const size_t tiles = std::max<size_t>(n_tiles, 64);
+    uint32_t cap[kWfLevels];
+    cap[0] = (uint32_t)(2 * tiles);
+    uint32_t deep = ctx->tune_wf_cap ? ctx->tune_wf_cap : (uint32_t)std::min<size_t>(std::max<size_t>(2 * tiles, 4096), (size_t)1 << 19);
+    deep = ((deep + kWfQueues - 1u) / kWfQueues) * kWfQueues;  // kWfQueues sub-queues of equal size
+    for (uint32_t k = 1; k < kWfLevels; ++k) cap[k] = deep;
+    const size_t pending_cap = (tiles + kWfQueues - 1) / kWfQueues + 1;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    const size_t o_header = off; off = up(off + (kWfRedoBase + kQueueBase + tiles) * 4);
+    const size_t o_pending = off; off = up(off + pending_cap * kWfQueues * 4);
+    const size_t o_mark = off; off = up(off + tiles * 4);
+    size_t o_items[kWfLevels], o_nodes[kWfLevels], o_rays[kWfLevels];
+    for (uint32_t k = 0; k < kWfLevels; ++k) { o_items[k] = off; off = up(off + (size_t)cap[k] * sizeof(WfItem)); }
+    const size_t zero_bytes = off;
+    for (uint32_t k = 0; k < kWfLevels; ++k) { o_nodes[k] = off; off = up(off + (size_t)cap[k] * kWfNodeWords * 4); }
+    for (uint32_t k = 1; k < kWfLevels; ++k) { o_rays[k] = off; off = up(off + (size_t)cap[k] * kWfRayWords * 4); }
+    o_rays[0] = o_rays[1];
+    HIP_TRY(ctx, hipMalloc((void**)&f.base, off));
+    f.bytes = off;
+    f.tiles = tiles;
+    f.cap_tune = ctx->tune_wf_cap;
+    f.zero_bytes = zero_bytes;
+    HIP_TRY(ctx, hipMemsetAsync(f.base, 0, zero_bytes, ctx->stream));
+    f.w.header = (uint32_t*)(f.base + o_header);
+    f.w.pending = (uint32_t*)(f.base + o_pending);
+    f.w.redo_mark = (uint32_t*)(f.base + o_mark);
+    f.w.pending_cap = (uint32_t)pending_cap;
+    for (uint32_t k = 0; k < kWfLevels; ++k) {
+        f.w.items[k] = (WfItem*)(f.base + o_items[k]);
+        f.w.nodes[k] = (uint32_t*)(f.base + o_nodes[k]);
+        f.w.rays[k] = (float*)(f.base + o_rays[k]);
+        f.w.cap[k] = cap[k];
+    }
+    return RT_OK;
+}
+
+// The launches of a wavefront frame behind classification and listing: level 0, the deeper levels the frame can
+// have, the combine, and render_kernel over the redo list.  Bracketed by one event pair when the launch is timed.
+int launch_wavefront(rt_ctx* ctx, const Params& p)
+{
+    int rc = listing(ctx, p, kVariantRender);
+    if (rc != RT_OK) return rc;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    const bool timed = ctx->timing && (ctx->timing_phase++ % ctx->timing_every == 0u);
+    if (timed) {
+        if (!ctx->event_pool.empty()) {
+            ev = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            HIP_TRY(ctx, hipEventCreate(&ev.first));
+            HIP_TRY(ctx, hipEventCreate(&ev.second));
+        }
+        HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
+    }
+    WfParams w = ctx->wf.w;
+    w.seq = ctx->wf.seq;
+    w.level = 0u;
+    hipError_t e = (hipError_t)launch_wf_trace(p, w, (void*)ctx->stream, ctx->max_workgroups);
+    if (e != hipSuccess) return fail_hip(ctx, e, "wavefront level-0 launch");
+    // children exist only if some material reflects or refracts, a light is on and the depth limit allows them
+    if (ctx->scene_has_children && p.n_lights != 0u && p.max_depth != 0u) {
+        for (uint32_t level = 1; level <= p.max_depth; ++level) {
+            w.level = level;
+            e = (hipError_t)launch_wf_trace(p, w, (void*)ctx->stream, ctx->max_workgroups);
+            if (e != hipSuccess) return fail_hip(ctx, e, "wavefront level launch");
+        }
+        e = (hipError_t)launch_wf_combine(p, w, (void*)ctx->stream, ctx->max_workgroups);
+        if (e != hipSuccess) return fail_hip(ctx, e, "wavefront combine launch");
+        Params redo = p;  // the tiles whose items did not fit: render_kernel traces them whole (usually none)
+        redo.queue = w.header + kWfRedoBase;
+        redo.qsel = 0u;
+        e = (hipError_t)launch_render(redo, kVariantRender, (void*)ctx->stream, 256u);
+        if (e != hipSuccess) return fail_hip(ctx, e, "wavefront redo launch");
+    }
+    if (timed) {
+        HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
+        ctx->events.push_back(ev);
+    }
+    return RT_OK;
+}
 
 // The host has just waited for the context's stream.  If a launch since the last check used the side kernel, read
 // the status word of the queue header back; non-zero = one of the device-side waits between the two streams (or
@@ -598,6 +711,7 @@ int rt_ctx_destroy(rt_ctx* ctx)
     (void)hipFree(ctx->own.cost);
     (void)hipFree(ctx->own.heavy);
     (void)hipFree(ctx->own.heavy_mark);
+    (void)hipFree(ctx->wf.base);
     (void)hipFree(ctx->d_part);
     if (ctx->part_done) (void)hipEventDestroy(ctx->part_done);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -912,6 +1026,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     for (size_t i = 0; i < n_materials; ++i)
         if (!(1.0f - materials[i].reflectivity - materials[i].transparency >= 0.01f)) b.dark_materials = 1u;
     if (ctx->tune_dark_kernel >= 0) b.dark_materials = ctx->tune_dark_kernel ? 1u : 0u;  // rt_set_tuning: either kernel for any scene
+    ctx->scene_has_children = false;  // cast_ray recurses where reflectivity > 0 or transparency > 0 (render.rs:154,172)
+    for (size_t i = 0; i < n_materials; ++i)
+        if (materials[i].reflectivity > 0.0f || materials[i].transparency > 0.0f) ctx->scene_has_children = true;
     b.atlas = ctx->d_atlas;
     b.n_cubes = (uint32_t)n_cubes;
     b.n_spheres = (uint32_t)n_spheres;
@@ -981,7 +1098,19 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     const size_t launch_tiles = (size_t)((frame->width + 7u) / 8u) * ((rt_part_rows(frame->y1 - frame->y0, n_parts, part) + 7u) / 8u);
     const uint32_t heavy_class = ctx->tune_heavy_class >= 0 ? (uint32_t)ctx->tune_heavy_class
                                  : ((synchronous && launch_tiles <= kAutoHeavyMaxTiles && ctx->base.n_chunks == 0u) ? kDefaultHeavyClass : kCostClasses);
-    const bool heavy_on = variant == kVariantRender && paints && heavy_class < kCostClasses && !ctx->heavy_disabled;
+    // The wavefront path (plain frames): a launch per ray-tree level over bundles of coherent rays instead of the
+    // tile-resident walk; explicit for now (RT_TUNE_WAVEFRONT).
+    const bool wavefront = variant == kVariantRender && ctx->tune_wavefront == 1;
+    if (wavefront) {
+        // the launch's tile grid (prepare): two tile rows per 16-row block of the part, a ragged last block included
+        const size_t wf_tiles = (size_t)((frame->width + 7u) / 8u) * 2u * ((rt_part_rows(frame->y1 - frame->y0, n_parts, part) + 15u) / 16u + 1u);
+        if ((rc = ensure_wavefront(ctx, wf_tiles)) != RT_OK) return rc;
+        if (++ctx->wf.seq == 0u) {  // wrapped: stale stamps could alias
+            HIP_TRY(ctx, hipMemsetAsync(ctx->wf.base, 0, ctx->wf.zero_bytes, ctx->stream));
+            ctx->wf.seq = 1u;
+        }
+    }
+    const bool heavy_on = variant == kVariantRender && paints && heavy_class < kCostClasses && !ctx->heavy_disabled && !wavefront;
     const uint32_t seq = ts.launch_seq;  // this launch's; prepare() increments it
     const uint32_t geom[6] = {frame->width, frame->height, frame->y0, frame->y1, n_parts, part};
     if (heavy_on && !ctx->stream_heavy) {
@@ -1010,7 +1139,7 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_heavy, ctx->heavy_fork, 0));
     }
     bool classified = false;
-    if ((rc = prepare(ctx, p, ts, heavy_on, heavy_now ? seq + 1u : 0u, &classified)) != RT_OK) return rc;
+    if ((rc = prepare(ctx, p, ts, heavy_on, heavy_now ? seq + 1u : 0u, &classified, wavefront ? ctx->wf.w.header : nullptr)) != RT_OK) return rc;
     // a buffer that had to grow took the list with it (no mark can match then: the fresh marks are zero), and
     // without classify_tiles (irregular camera) nobody would say go
     heavy_now = heavy_now && ts.heavy_list_ready && (classified || by_events);
@@ -1043,6 +1172,7 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
             p.prefilled = 1u;
         }
     }
+    if (wavefront) return launch_wavefront(ctx, p);
     if ((rc = launch_timed(ctx, p, variant)) != RT_OK) return rc;
     if (heavy_now) {
         ctx->heavy_unchecked = true;
@@ -1360,6 +1490,15 @@ int rt_set_tuning(rt_ctx* ctx, int key, double value)
         ctx->tune_heavy_spin = (uint32_t)value;
         if (value == 0.0) ctx->heavy_disabled = false;  // the default restores a side kernel that a give-up took out of service
         return RT_OK;
+    case RT_TUNE_WAVEFRONT:
+        if (!tri) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_WAVEFRONT must be -1 (automatic), 0 or 1");
+        ctx->tune_wavefront = (int)value;
+        return RT_OK;
+    case RT_TUNE_WAVEFRONT_CAP:
+        if (!(value >= 0.0 && value <= (double)(1u << 22) && value == (double)(uint32_t)value))
+            return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_WAVEFRONT_CAP must be an integer in 0..2^22 (0: from the frame size)");
+        ctx->tune_wf_cap = (uint32_t)value;
+        return RT_OK;
     case RT_TUNE_BVH_DEPTH_LIMIT:
         if (!(value >= 1.0 && value <= (double)kBvhStackMax && value == (double)(uint32_t)value))
             return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_BVH_DEPTH_LIMIT must be an integer in 1..28");
@@ -1543,6 +1682,34 @@ int rt_debug_tile_costs(rt_ctx* ctx, uint32_t* out, size_t cap, size_t* out_tile
     *out_tiles = tiles;
     const size_t n = cap < tiles ? cap : tiles;
     if (out && n) HIP_TRY(ctx, hipMemcpy(out, ctx->own.cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_debug_wavefront_items(rt_ctx* ctx, uint32_t level, uint32_t* out_words, size_t cap_items, size_t* out_items)
+{
+    if (!ctx || !out_items || level >= kWfLevels) return fail(ctx, RT_ERR_INVALID_ARG, "null argument or level > 3");
+    *out_items = 0;
+    ENTER_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->wf.base) return RT_OK;
+    std::vector<WfItem> all;
+    if (level == 0u) {
+        all.resize(ctx->wf.w.cap[0]);
+        HIP_TRY(ctx, hipMemcpy(all.data(), ctx->wf.w.items[0], all.size() * sizeof(WfItem), hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint32_t> hdr(kWfRedoBase);
+        HIP_TRY(ctx, hipMemcpy(hdr.data(), ctx->wf.w.header, hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t cap = ctx->wf.w.cap[level] / kWfQueues;
+        for (uint32_t q = 0; q < kWfQueues; ++q) {
+            const uint32_t n = std::min(hdr[((level - 1u) * kWfQueues + q) * 16u], cap);
+            const size_t at = all.size();
+            all.resize(at + n);
+            if (n) HIP_TRY(ctx, hipMemcpy(all.data() + at, ctx->wf.w.items[level] + (size_t)q * cap, n * sizeof(WfItem), hipMemcpyDeviceToHost));
+        }
+    }
+    *out_items = all.size();
+    const size_t n = std::min<size_t>(cap_items, all.size());
+    if (out_words && n) std::memcpy(out_words, all.data(), n * sizeof(WfItem));
     return RT_OK;
 }
 

@@ -196,12 +196,57 @@ struct TileParams {
     uint32_t qsel;
     uint32_t heavy_on;  // the launch keeps a heavy list: block 0 works out which cost classes fit (kHeavyClassWord)
     uint32_t heavy_go;  // Params::heavy_now of the launch (0: no side kernel): block 0 stores it to queue[kHeavyGoWord]
+    uint32_t* wf_header;  // wavefront launches: block 0 zeroes the counters of WfParams::header (null otherwise)
 };
 constexpr uint32_t kStampBase = 64;  // first per-tile word
 constexpr uint32_t kQueueBase = 64;  // first tile entry of Params::queue
 constexpr uint32_t kCostClasses = 8;
 
 enum KernelVariant { kVariantRender = 0, kVariantDebug = 1, kVariantCount = 2 };
+
+// ---- the wavefront path: one launch per ray-tree level instead of a tile-resident walk of the whole tree
+// (cast_ray's recursion, reference src/render.rs:154-193).  A launch traces ITEMS: bundles of up to 64 rays of one
+// level that left one parent wave through the same kind of child (reflection / refraction) off the same cube face,
+// i.e. coherent rays, whatever the tile looked like.  Level 0 = the primary rays of a traced tile (one item per
+// pass); an item that spawns children allocates their items and ray blocks with one atomic add; the last launch
+// (wf_combine_kernel) folds every tile's item tree bottom-up with node_finish, in the reference's operation order,
+// and writes the pixels.  A tile whose items did not fit the buffers is rendered again by render_kernel (redo list).
+struct WfItem {            // 32 B, wave-uniform
+    uint32_t parent;       // the parent item (index in the level above); level 0: unused
+    uint32_t info;         // bit 0: child kind (0 reflection, 1 refraction), bit 1: pass (PASS_SPHERES / PASS_CUBES)
+    uint32_t mask_lo, mask_hi;  // the lanes (pixels of the root tile) that have a ray in this bundle
+    uint32_t entry;        // the root tile's queue entry (column | no-cubes flag << 15 | row << 16)
+    uint32_t first_child, n_children;  // written by the wave that traces the item: its child items, level + 1
+    uint32_t stamp;        // WfParams::seq of the launch that wrote the item (anything else: not an item of this launch)
+};
+static_assert(sizeof(WfItem) == 32, "WfItem must be one dwordx8");
+constexpr uint32_t kWfLevels = 4;          // ray-tree depths 0..3 (max_depth <= 3)
+constexpr uint32_t kWfBundles = 3;         // bundles a wave's children of one kind are split into at most (by face; the last takes the rest)
+constexpr uint32_t kWfNodeWords = 2 * 64;  // per item: packed light sum | hit flag, material index; per lane
+constexpr uint32_t kWfRayWords = 6 * 64;   // per item: origin, direction; per lane
+// Allocation counters.  A same-address atomic add costs the device about 3 ns, and the waves of a level reach their
+// allocation at about the same time: 6 000 of them queued behind one counter wait 10 us on average (measured: 50 K
+// of a level-1 item's 80 K cycles).  Every level therefore has kWfQueues sub-queues with a counter each, a cache line
+// apart; a wave allocates in the sub-queue of its own item index modulo kWfQueues, and the next launch's workgroup b
+// serves sub-queue b % kWfQueues.  Item index = sub-queue * (cap / kWfQueues) + position.  The same for the list of
+// pending roots.  WfParams::header: counter c at word 16 c - c = (level - 1) * kWfQueues + q for levels 1..3, then
+// the kWfQueues pending counters -, then the redo list as a queue in render_kernel's format (its header bank 0 at
+// word kWfRedoBase, entries from kWfRedoBase + kQueueBase).
+constexpr uint32_t kWfQueues = 64;
+constexpr uint32_t kWfPendingCounter = 3 * kWfQueues;                     // first pending counter
+constexpr uint32_t kWfRedoBase = (kWfPendingCounter + kWfQueues) * 16;    // = 4096
+struct WfParams {
+    WfItem* items[kWfLevels];     // level 0: 2 items per traced tile (index 2 * tile's queue position + pass)
+    uint32_t* nodes[kWfLevels];   // [item][2][64]
+    float* rays[kWfLevels];       // [item][6][64], levels 1..3
+    uint32_t cap[kWfLevels];      // items per level (levels 1..3: a multiple of kWfQueues)
+    uint32_t pending_cap;         // entries per pending sub-list
+    uint32_t* header;             // counters, then the redo queue (one entry per tile of the launch at most)
+    uint32_t* pending;            // level-0 positions of the tiles whose items wait for children
+    uint32_t* redo_mark;          // per tile of the launch: == seq when the tile is on the redo list
+    uint32_t seq;                 // stamp of this launch (only grows)
+    uint32_t level;               // the level a wf_trace_kernel launch traces
+};
 
 // Launches the render kernel for rows [y0,y1) on `stream` (hipStream_t passed as void*).
 // Returns a hipError_t as int.
@@ -216,6 +261,10 @@ int launch_heavy(const Params& p, void* stream, bool gate);
 // tile of the launch's list (a kernel behind a kernel costs the stream 2-3 us, an event wait 9)
 int launch_heavy_join(const Params& p, void* stream);
 int launch_classify(const TileParams& t, void* stream);
+// wavefront path: level 0 (striding over the tile queue like render_kernel), then one launch per deeper level
+// (w.level), the combine launch, and render_kernel over the redo list
+int launch_wf_trace(const Params& p, const WfParams& w, void* stream, uint32_t max_workgroups);
+int launch_wf_combine(const Params& p, const WfParams& w, void* stream, uint32_t max_workgroups);
 // selftest_division: blocks x 256 threads x iters operand pairs; d_out[0] += mismatches, d_out[1] += cases
 int launch_selftest_division(uint32_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out, void* stream);
 

@@ -1370,6 +1370,7 @@ template <bool DBG, bool SPLIT = false>
 constexpr int frame_words() { return DBG ? 12 : (SPLIT ? 11 : 10); }
 constexpr int F_KEY = 10;  // SPLIT (plain variants only): the bundle key of the node's refraction child
 constexpr uint32_t kHitFlag = 1u << 24;  // in F_SUMF, above the packed 0x00RRGGBB light sum
+constexpr uint32_t RT_MAX_DEPTH_C = 3u;  // deepest level that is traced (rtx950.h RT_MAX_DEPTH; check_frame refuses more)
 
 // min(255, sum + L*trunc(c_refl*k_r) + L*trunc(c_refr*k_t)) for lanes with a hit, sky otherwise
 DEV uint32_t node_finish(const Params& P, uint32_t sumf, float k_r, float k_t, uint32_t c_refl, uint32_t c_refr)
@@ -2220,6 +2221,344 @@ __global__ __launch_bounds__(64) void heavy_join(const Params P)
     if (gave_up && threadIdx.x == 0u) P.queue[kQueueBase - 1u] = 3u;
 }
 
+// ---------------------------------------------------------------- the wavefront path (WfParams, rtx950_device.h)
+// cast_ray's recursion (render.rs:154-193) as one launch per ray-tree level.  The tile-resident walk above keeps a
+// tile on one wave from its primary rays to the last grandchild: a chain of up to four nodes with three list
+// traversals each, and after the first bounce the 64 lanes of a tile across a cube edge go several ways, so the
+// wave-level cull keeps every cube.  Here a node is traced by the wave of its ITEM: the rays of one level that
+// left one parent wave through the same kind of child off the same cube face.  Such rays are coherent whatever the
+// tile looked like, a launch's critical path is one node, and the deeper levels of all tiles fill the GPU together.
+// Every pixel is computed by the same functions in the same arithmetic as in trace_tree (nearest_query,
+// cube_resolve, light_term, reflect/refract, node_finish); only the wave that executes them differs.
+struct WfNode {
+    uint32_t sumf;   // packed light sum | kHitFlag
+    uint32_t mat;    // material index of the hit (0 without one)
+    uint32_t face;   // cube face of the hit: the bundle key of the node's children
+    bool has_refl, has_refr;
+    V3 refl_o, refl_d, refr_o, refr_d;
+};
+
+// One node of cast_ray for the wave's rays: render.rs:87-152 and the child rays of :154-193 (trace_tree's node
+// code without the tree walk around it).
+template <bool LARGE, bool DARK>
+DEV WfNode wf_node(const Params& P, uint32_t pass, bool act, V3 o, V3 d, float ambient PROF_ARG)
+{
+    WfNode r;
+    Counters cnt = {};
+    bool div_ok;
+    const uint32_t idx = nearest_query<false, LARGE>(P, pass, act, o, d, div_ok, cnt, 0u PROF_PASS);
+    const bool hit_any = act && (idx != kNoHit);
+    Col sum = Col{0.0f, 0.0f, 0.0f};
+    r.mat = 0u;
+    r.face = 0u;
+    r.has_refl = false;
+    r.has_refr = false;
+    r.refl_o = o; r.refl_d = d; r.refr_o = o; r.refr_d = d;
+    if (wave_any(hit_any)) {
+        const uint32_t sidx = hit_any ? idx : 0u;  // lanes without a hit shade object 0 and discard the result
+        Hit hit;
+        if (pass == PASS_CUBES) hit = cube_resolve(P, sidx, o, d, div_ok);
+        else hit = sphere_resolve(P, sidx, o, d);
+        const MatRec m = P.mats[hit.material];
+        Col tx;
+        if (m.texture >= 0) tx = texel_of_face(P, m.texture, hit.face, hit.u * P.sprite, hit.v * P.sprite);
+        else tx = col_from_hex(m.diffuse_0rgb);
+        const Col tx_a = col_mul(tx, m.albedo0);
+        const V3 view_dir = vnormalize(vsub(o, hit.p));
+        const float k_ds = 1.0f - m.reflectivity - m.transparency;
+        const uint32_t nl = P.n_lights;
+        bool lit = hit_any;
+        uint32_t nl_cast = nl;
+        if constexpr (DARK) {  // direct light that is exactly black casts no shadow rays (see trace_tree)
+            lit = hit_any && !(k_ds < 0.0039f);
+            nl_cast = wave_any(lit) ? nl : 0u;
+        }
+        uint32_t h_unused = 0u;
+        for (uint32_t li = 0; li < nl_cast; ++li) {
+            const Col term = light_term<false, false, LARGE>(P, pass, li, lit, hit_any, hit.p, hit.n, hit.id, view_dir, tx_a, m.specular, m.albedo1, k_ds,
+                                                             ambient, h_unused, cnt, 0u PROF_PASS);
+            sum = col_add(sum, term);
+        }
+        // children (render.rs:154-193); the reference casts them inside the light loop: without lights there are none
+        r.has_refl = hit_any && (m.reflectivity > 0.0f) && (nl != 0u);
+        r.has_refr = hit_any && (m.transparency > 0.0f) && (nl != 0u);
+        if (wave_any(r.has_refl || r.has_refr)) {
+            r.refl_d = vnormalize(reflect(vneg(d), hit.n));
+            r.refl_o = vadd(hit.p, vscale(hit.n, 1e-2f));
+            r.refr_d = refract(d, hit.n, m.ior);
+            r.refr_o = vadd(hit.p, vscale(hit.n, 1e-3f));
+        }
+        r.mat = hit_any ? hit.material : 0u;
+        r.face = (uint32_t)hit.face;
+    }
+    r.sumf = col_to_hex(sum) | (hit_any ? kHitFlag : 0u);
+    return r;
+}
+
+DEV WfItem wf_load_item(const WfItem* base, uint32_t i)
+{
+    const u32x8 v = ((KCONST u32x8*)base)[i];
+    const uint32_t e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3], e4 = v[4], e5 = v[5], e6 = v[6], e7 = v[7];
+    return WfItem{e0, e1, e2, e3, e4, e5, e6, e7};
+}
+
+// The tile behind `entry` cannot be finished by the wavefront launches (its items did not fit): render_kernel
+// traces it whole after them.  Once per tile and launch.
+DEV void wf_mark_redo(const Params& P, const WfParams& W, uint32_t entry)
+{
+    if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t t = (entry >> 16) * P.grid_tx + (entry & 0x7FFFu);
+        if (atomicExch(&W.redo_mark[t], W.seq) != W.seq) {
+            const uint32_t slot = atomicAdd(&W.header[kWfRedoBase], 1u);
+            W.header[kWfRedoBase + kQueueBase + slot] = entry;  // at most one entry per tile of the launch
+        }
+    }
+}
+
+// The bundles of the lanes in `m`: lanes whose node hit the same face go together, the kWfBundles-th takes the rest.
+// f(sel, j) is called per bundle j with its lane mask; returns the number of bundles.  Wave-uniform.
+template <typename F>
+DEV uint32_t wf_split(unsigned long long m, uint32_t face, F f)
+{
+    uint32_t nb = 0u;
+    while (m != 0ull) {
+        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)face, (int)__builtin_ctzll(m));
+        const unsigned long long sel = (nb + 1u == kWfBundles) ? m : (m & wave_ballot(face == f0));
+        f(sel, nb);
+        m &= ~sel;
+        ++nb;
+    }
+    return nb;
+}
+
+// The children of the node `n` of item `item` at `level`: one item per kind and bundle at level + 1, their rays
+// stored per lane.  One atomic add per emitting wave.
+DEV void wf_emit(const Params& P, const WfParams& W, uint32_t level, uint32_t item, uint32_t pass, uint32_t entry, const WfNode& n, uint32_t& first_child,
+                 uint32_t& n_children)
+{
+    first_child = 0u;
+    n_children = 0u;
+    if (!(level < P.max_depth)) return;  // children beyond max_depth return the sky colour without tracing (render.rs:80-82)
+    const unsigned long long m_refl = wave_ballot(n.has_refl), m_refr = wave_ballot(n.has_refr);
+    if ((m_refl | m_refr) == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t want = wf_split(m_refl, n.face, [](unsigned long long, uint32_t) {}) + wf_split(m_refr, n.face, [](unsigned long long, uint32_t) {});
+    // allocation in the sub-queue of this item's index (see kWfQueues)
+    const uint32_t sq = item & (kWfQueues - 1u);
+    const uint32_t cap = W.cap[level + 1u] / kWfQueues;
+    uint32_t base = 0u;
+    if (lane == 0u) base = atomicAdd(&W.header[(level * kWfQueues + sq) * 16u], want);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= cap || want > cap - base) {
+        wf_mark_redo(P, W, entry);
+        return;
+    }
+    base += sq * cap;
+    WfItem* items = W.items[level + 1u];
+    float* rays = W.rays[level + 1u];
+    uint32_t ci = base;
+    for (uint32_t kind = 0u; kind < 2u; ++kind) {
+        const V3 co = kind ? n.refr_o : n.refl_o, cd = kind ? n.refr_d : n.refl_d;
+        wf_split(kind ? m_refr : m_refl, n.face, [&](unsigned long long sel, uint32_t) {
+            if ((sel >> lane) & 1ull) {
+                float* r = rays + (size_t)ci * kWfRayWords + lane;
+                r[0 * 64] = co.x; r[1 * 64] = co.y; r[2 * 64] = co.z;
+                r[3 * 64] = cd.x; r[4 * 64] = cd.y; r[5 * 64] = cd.z;
+            }
+            if (lane == 0u) {
+                u32x8 rec = {item, kind | (pass << 1), (uint32_t)sel, (uint32_t)(sel >> 32), entry, 0u, 0u, W.seq};
+                *(u32x8*)(items + ci) = rec;
+            }
+            ++ci;
+        });
+    }
+    first_child = base;
+    n_children = want;
+}
+
+template <bool PRIMARY, bool LARGE, bool DARK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU, LARGE ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU))) void wf_trace_kernel(const Params P, const WfParams W)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    PROF_DECL
+    if constexpr (PRIMARY) {
+        // level 0: the traced tiles of the queue, heaviest first, as in render_kernel.  A work unit is one PASS of a
+        // tile (render.rs:248-306: spheres with ambient 1, cubes with ambient_light): one unit per tile when the scene
+        // has no spheres, two otherwise, so that the node code below has no loop around it (a pass loop around it
+        // doubled the kernel's spills).
+        const uint32_t two = P.n_spheres != 0u ? 1u : 0u;
+        for (uint32_t unit = blockIdx.x;; unit += gridDim.x) {
+            const unsigned long long t_start = __builtin_readcyclecounter();
+            const uint32_t item = unit >> two;
+            const uint32_t pass = two ? (unit & 1u) : (uint32_t)PASS_CUBES;
+            uint32_t idx = item, entry = 0xFFFFFFFFu;
+            const uint32_t tiles = P.grid_tx * P.grid_ty;
+            KCONST uint32_t* q = (KCONST uint32_t*)P.queue;
+            bool found = false;
+            for (uint32_t k = kCostClasses; k-- > 0u;) {
+                const uint32_t n_k = q[P.qsel * 16u + k];
+                if (!found && idx < n_k) {
+                    entry = q[kQueueBase + k * tiles + idx];
+                    found = true;
+                }
+                idx -= found ? 0u : n_k;
+            }
+            if (!found) break;  // plain frames list no paint-only tiles (build_queue paints them)
+            const uint32_t bx = entry & 0x7FFFu, by = entry >> 16;
+            const uint32_t x = bx * 8u + (lane & 7u);
+            const uint32_t y = tile_y0(P, by) + (lane >> 3);
+            const bool active = (x < P.width) && (y < P.y1);
+            // a pass that cannot hit anything is not traced: its root stays "no hit" (the sky colour)
+            const bool skip = (pass == PASS_SPHERES) ? (P.n_spheres == 0u) : ((entry & kEntryNoCubes) != 0u);
+            WfNode n;
+            n.sumf = 0u; n.mat = 0u; n.face = 0u; n.has_refl = false; n.has_refr = false;
+            uint32_t fc = 0u, nc = 0u;
+            if (!skip) {
+                // render.rs:253-263, camera.rs:38-40
+                const float width = (float)P.width, height = (float)P.height;
+                const float aspect = width / height;
+                float sx = (2.0f * (float)x) / width - 1.0f;
+                const float sy = -(2.0f * (float)y) / height + 1.0f;
+                sx = sx * aspect;
+                const V3 v = vnormalize(v3(sx, sy, -1.0f));
+                const V3 right = v3(P.right[0], P.right[1], P.right[2]), up = v3(P.up[0], P.up[1], P.up[2]), fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
+                const V3 dir = vnormalize(vsub(vadd(vscale(right, v.x), vscale(up, v.y)), vscale(fwd, v.z)));
+                n = wf_node<LARGE, DARK>(P, pass, active, v3(P.eye[0], P.eye[1], P.eye[2]), dir, pass == PASS_SPHERES ? 1.0f : P.ambient PROF_PASS);
+                wf_emit(P, W, 0u, 2u * item + pass, pass, entry, n, fc, nc);
+            }
+            if (!two && nc == 0u) {
+                // one pass and no traced children: the pixel is final (the sphere pass is the sky colour, so the merge
+                // of render.rs:308-312 takes this pass; children beyond max_depth are the sky colour)
+                const MatRec* mp = P.mats + n.mat;
+                const float k_r = mp->reflectivity, k_t = mp->transparency;
+                const bool hit_any = (n.sumf & kHitFlag) != 0u;
+                const bool has_refl = hit_any && (k_r > 0.0f) && (P.n_lights != 0u);
+                const bool has_refr = hit_any && (k_t > 0.0f) && (P.n_lights != 0u);
+                const uint32_t zero = 0u;
+                uint32_t px = node_finish(P, n.sumf, k_r, k_t, has_refl ? P.sky : zero, has_refr ? P.sky : zero);
+                if ((size_t)y * P.width + x == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
+                if (active && P.out) P.out[(size_t)(by * 8u + (lane >> 3)) * P.width + x] = px;
+            } else {
+                // the root waits: wf_combine_kernel finishes the tile from both passes' roots
+                const unsigned long long am = wave_ballot(active);
+                const uint32_t ri = 2u * item + pass;
+                uint32_t* nd = W.nodes[0] + (size_t)ri * kWfNodeWords + lane;
+                nd[0] = n.sumf;
+                nd[64] = n.mat;
+                if (lane == 0u) {
+                    u32x8 rec = {0u, pass << 1, (uint32_t)am, (uint32_t)(am >> 32), entry, fc, nc, W.seq};
+                    *(u32x8*)(W.items[0] + ri) = rec;
+                    if (pass == PASS_CUBES) {  // once per tile
+                        const uint32_t sq = item & (kWfQueues - 1u);  // at most ceil(tiles / kWfQueues) positions map here: it cannot overflow
+                        W.pending[sq * W.pending_cap + atomicAdd(&W.header[(kWfPendingCounter + sq) * 16u], 1u)] = item;
+                    }
+                }
+            }
+            if (lane == 0u && pass == PASS_CUBES) P.tile_cost[(size_t)by * P.grid_tx + bx] = (uint32_t)(__builtin_readcyclecounter() - t_start) | 1u;
+        }
+    } else {
+        const uint32_t level = W.level;
+        KCONST uint32_t* hdr = (KCONST uint32_t*)W.header;
+        // workgroup b serves sub-queue b % kWfQueues (the grid is a multiple of kWfQueues)
+        const uint32_t sq = blockIdx.x & (kWfQueues - 1u);
+        const uint32_t cap = W.cap[level] / kWfQueues;
+        uint32_t n = hdr[((level - 1u) * kWfQueues + sq) * 16u];
+        n = n < cap ? n : cap;
+        const WfItem* items = W.items[level];
+        const float* rays = W.rays[level];
+        for (uint32_t j = blockIdx.x / kWfQueues; j < n; j += gridDim.x / kWfQueues) {
+            const uint32_t it = sq * cap + j;
+            const unsigned long long t_item = __builtin_readcyclecounter();
+            const WfItem rec = wf_load_item(items, it);
+            if (rec.stamp != W.seq) continue;  // an allocation that did not fit left a hole (its tile is on the redo list)
+            const unsigned long long mask = ((unsigned long long)rec.mask_hi << 32) | rec.mask_lo;
+            const bool act = ((mask >> lane) & 1ull) != 0ull;
+            const float* r = rays + (size_t)it * kWfRayWords + lane;
+            V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 0.0f);
+            if (act) {
+                o = v3(r[0 * 64], r[1 * 64], r[2 * 64]);
+                d = v3(r[3 * 64], r[4 * 64], r[5 * 64]);
+            }
+            const uint32_t pass = (rec.info >> 1) & 1u;
+            const WfNode nd = wf_node<LARGE, DARK>(P, pass, act, o, d, pass == PASS_SPHERES ? 1.0f : P.ambient PROF_PASS);
+            uint32_t fc, nc;
+            wf_emit(P, W, level, it, pass, rec.entry, nd, fc, nc);
+            uint32_t* out = W.nodes[level] + (size_t)it * kWfNodeWords + lane;
+            out[0] = nd.sumf;
+            out[64] = nd.mat;
+            if (lane == 0u) {
+                u32x2 cw = {fc, nc};
+                *(u32x2*)&W.items[level][it].first_child = cw;
+                W.items[level][it].parent = (uint32_t)(__builtin_readcyclecounter() - t_item);  // diagnostic (rt_debug_wavefront_items); nothing reads the parent link
+            }
+        }
+    }
+}
+
+// The colour of item `it` of LEVEL per lane (valid for the lanes of its mask): its children's colours first
+// (depth-first over the item tree, post-order), then node_finish - cast_ray's fold of render.rs:221-224 in the
+// closed form described at node_finish, children in the reference's order (reflection, refraction).
+template <uint32_t LEVEL>
+DEV uint32_t wf_finish(const Params& P, const WfParams& W, uint32_t it, const WfItem& rec)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t* nd = W.nodes[LEVEL] + (size_t)it * kWfNodeWords + lane;
+    const uint32_t sumf = nd[0], mat = nd[64];
+    const MatRec* mp = P.mats + mat;
+    const float k_r = mp->reflectivity, k_t = mp->transparency;
+    const bool hit_any = (sumf & kHitFlag) != 0u;
+    const bool has_refl = hit_any && (k_r > 0.0f) && (P.n_lights != 0u);
+    const bool has_refr = hit_any && (k_t > 0.0f) && (P.n_lights != 0u);
+    uint32_t c_refl = P.sky, c_refr = P.sky;  // children beyond max_depth
+    if constexpr (LEVEL < RT_MAX_DEPTH_C) {
+        if (LEVEL < P.max_depth) {
+            c_refl = 0u;
+            c_refr = 0u;
+            for (uint32_t j = 0; j < rec.n_children; ++j) {
+                const uint32_t ch = rec.first_child + j;
+                const WfItem crec = wf_load_item(W.items[LEVEL + 1u], ch);
+                const uint32_t c = wf_finish<LEVEL + 1u>(P, W, ch, crec);
+                const unsigned long long cm = ((unsigned long long)crec.mask_hi << 32) | crec.mask_lo;
+                const bool in = ((cm >> lane) & 1ull) != 0ull;
+                if (crec.info & 1u) c_refr = in ? c : c_refr;
+                else c_refl = in ? c : c_refl;
+            }
+        }
+    }
+    const uint32_t zero = 0u;
+    return node_finish(P, sumf, k_r, k_t, has_refl ? c_refl : zero, has_refr ? c_refr : zero);
+}
+
+// One wave per tile whose roots wait for children: both passes' trees, the merge of render.rs:308-312, the pixel.
+__global__ __launch_bounds__(64) void wf_combine_kernel(const Params P, const WfParams W)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    KCONST uint32_t* hdr = (KCONST uint32_t*)W.header;
+    const uint32_t sq = blockIdx.x & (kWfQueues - 1u);
+    const uint32_t n = hdr[(kWfPendingCounter + sq) * 16u];
+    for (uint32_t i = blockIdx.x / kWfQueues; i < n; i += gridDim.x / kWfQueues) {
+        const uint32_t item = ((KCONST uint32_t*)W.pending)[sq * W.pending_cap + i];
+        uint32_t px = 0u, entry = 0u;
+        for (uint32_t pass = PASS_SPHERES; pass <= PASS_CUBES; ++pass) {
+            uint32_t c = P.sky;
+            if (pass == PASS_CUBES || P.n_spheres != 0u) {  // without spheres level 0 writes no sphere roots: that pass is the sky colour
+                const uint32_t ri = 2u * item + pass;
+                const WfItem rec = wf_load_item(W.items[0], ri);
+                entry = rec.entry;
+                c = wf_finish<0u>(P, W, ri, rec);
+            }
+            if (pass == PASS_SPHERES) px = c;
+            else px = (px == P.sky) ? c : px;
+        }
+        const uint32_t bx = entry & 0x7FFFu, by = entry >> 16;
+        const uint32_t x = bx * 8u + (lane & 7u);
+        const uint32_t y = tile_y0(P, by) + (lane >> 3);
+        const uint32_t out_row = by * 8u + (lane >> 3);
+        if ((size_t)y * P.width + x == (size_t)P.width) px = 0u;  // render.rs:316-322: pixel i == width is never painted
+        if ((x < P.width) && (y < P.y1) && P.out) P.out[(size_t)out_row * P.width + x] = px;
+    }
+}
+
 // ---------------------------------------------------------------- classify_tiles
 // Which 8x8 pixel tiles can contain a primary ray that meets a cube?  A pixel's ray is the line
 // eye + t (sx right + sy up + fwd) with sx = (2x/W - 1) W/H, sy = 1 - 2y/H (render.rs:245-262,
@@ -2258,6 +2597,10 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
         // caller did with the output buffer).  A device-coherent store: the waiting waves run on any XCD.
         if (lane == 0u && T.heavy_go != 0u) __hip_atomic_store(&T.queue[kHeavyGoWord], T.heavy_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane < 16u) T.queue[(T.qsel ^ 1u) * 16u + lane] = 0u;  // the queue header bank of the NEXT launch
+        if (T.wf_header) {  // a wavefront launch: its item counters, pending count and redo list start at zero
+            for (uint32_t c = lane; c < kWfPendingCounter + kWfQueues; c += 64u) T.wf_header[c * 16u] = 0u;  // every sub-queue's counter
+            if (lane < 16u) T.wf_header[kWfRedoBase + lane] = 0u;
+        }
     }
     if (cube >= T.n_cubes) return;
     const float* rec = T.cube_filt + (size_t)cube * 4u;
@@ -2400,6 +2743,43 @@ int launch_render(const Params& p, int variant, void* stream, uint32_t max_workg
         }
         break;
     }
+    return (int)hipGetLastError();
+}
+
+int launch_wf_trace(const Params& p, const WfParams& w, void* stream, uint32_t max_workgroups)
+{
+    const uint32_t tiles = p.grid_tx * p.grid_ty;
+    if (tiles == 0u) return (int)hipSuccess;
+    const bool primary = w.level == 0u;
+    // deeper levels: the item count is only known on the device; a grid of a few thousand workgroups (a multiple of
+    // kWfQueues) strides over the sub-queues
+    const uint32_t units = p.n_spheres != 0u ? 2u * tiles : tiles;  // level 0: a work unit per tile and traced pass
+    uint32_t g = primary ? (units < max_workgroups ? units : max_workgroups) : (max_workgroups < 8192u ? max_workgroups : 8192u);
+    if (!primary) g = g < kWfQueues ? kWfQueues : (g / kWfQueues) * kWfQueues;
+    dim3 grid(g, 1u, 1u), block(64u, 1u, 1u);
+    hipStream_t s = (hipStream_t)stream;
+    const bool large = p.n_chunks > 0u, dark = p.dark_materials != 0u;
+    const uint32_t lds = large ? p.bvh_levels * 256u : 0u;
+#define RTX_WF_LAUNCH(PRIM, LG, DK) hipLaunchKernelGGL((wf_trace_kernel<PRIM, LG, DK>), grid, block, lds, s, p, w)
+    if (primary) {
+        if (large) { if (dark) RTX_WF_LAUNCH(true, true, true); else RTX_WF_LAUNCH(true, true, false); }
+        else { if (dark) RTX_WF_LAUNCH(true, false, true); else RTX_WF_LAUNCH(true, false, false); }
+    } else {
+        if (large) { if (dark) RTX_WF_LAUNCH(false, true, true); else RTX_WF_LAUNCH(false, true, false); }
+        else { if (dark) RTX_WF_LAUNCH(false, false, true); else RTX_WF_LAUNCH(false, false, false); }
+    }
+#undef RTX_WF_LAUNCH
+    return (int)hipGetLastError();
+}
+
+int launch_wf_combine(const Params& p, const WfParams& w, void* stream, uint32_t max_workgroups)
+{
+    const uint32_t tiles = p.grid_tx * p.grid_ty;
+    if (tiles == 0u) return (int)hipSuccess;
+    uint32_t g = max_workgroups < 8192u ? max_workgroups : 8192u;
+    g = g < kWfQueues ? kWfQueues : (g / kWfQueues) * kWfQueues;
+    dim3 grid(g, 1u, 1u), block(64u, 1u, 1u);
+    hipLaunchKernelGGL(wf_combine_kernel, grid, block, 0, (hipStream_t)stream, p, w);
     return (int)hipGetLastError();
 }
 

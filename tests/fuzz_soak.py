@@ -4,7 +4,9 @@ over many seeds (GPU through the C-ABI against the oracle: hit planes and ray-tr
 within 1 LSB on >= 99.9 % of pixels, ray counters equal).  Prints one line per failing seed and a summary.
 RTX950_SOAK_HEAVY=k (read here, by the tool): also renders every scene three more times with
 rt_set_tuning(RT_TUNE_HEAVY_CLASS, k), so that the side kernel (three-wave workgroups, general cull, bundles)
-traces the tiles of cost class >= k; those frames must equal the debug variant's too."""
+traces the tiles of cost class >= k; those frames must equal the debug variant's too.
+RTX950_SOAK_WAVEFRONT=1: the plain frames are rendered by the wavefront launches (RT_TUNE_WAVEFRONT), twice each,
+every third scene with the item capacity cut to 128 (RT_TUNE_WAVEFRONT_CAP: overflowing tiles take the redo list)."""
 import os
 import sys
 
@@ -21,6 +23,7 @@ max_cubes = int(sys.argv[3]) if len(sys.argv) > 3 else None
 base = rt.default_scene()
 ctx = rt.Context(0)
 soak_heavy = os.environ.get("RTX950_SOAK_HEAVY")
+soak_wf = os.environ.get("RTX950_SOAK_WAVEFRONT") == "1"
 bad = 0
 worst = 1.0
 for seed in range(first, first + count):
@@ -28,7 +31,15 @@ for seed in range(first, first + count):
     ctx.upload(sc)
     f = sc.frame(96, 64)
     gfb, gpl = ctx.render(f, debug=True)
+    if soak_wf:
+        ctx.set_tuning(rt.RT_TUNE_WAVEFRONT, 1)
+        ctx.set_tuning(rt.RT_TUNE_WAVEFRONT_CAP, 128 if seed % 3 == 0 else 0)
+        first_plain = ctx.render(f)
     plain = ctx.render(f)  # the kernel variant that ships
+    if soak_wf:
+        ctx.set_tuning(rt.RT_TUNE_WAVEFRONT, -1)
+        if not (first_plain == plain).all():
+            plain = first_plain  # report below
     ofb, opl, ocnt, _ = orc.OracleScene(sc).render(f, debug=True, reuse_secondary=True)
     try:
         rep = assert_parity(gfb, gpl, ofb, opl, label)

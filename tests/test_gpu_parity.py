@@ -692,8 +692,84 @@ def test_side_kernel_moving_camera_empty_and_full_lists():
             c.close()
 
 
+def _wavefront_cases():
+    s = rt.default_scene()
+    water = rt.default_scene(with_water=True)
+    lights16 = [rt.Light(rt.Vec3(-8.0 + k, 6.0 + 0.5 * k, 9.0 - 1.3 * k), 0x102030 * (k % 7 + 1) & 0xFFFFFF, 0.05 + 0.07 * k) for k in range(16)]
+    three = rt.make_scene(list(s.cubes), [], list(s.materials), lights16[:3], s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
+    none = rt.make_scene(list(s.cubes), [], list(s.materials), [], s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
+    return [("diorama", s, 480, 270, {}), ("water", water, 480, 270, {}), ("water depth 1", water, 200, 120, {"max_depth": 1}),
+            ("water depth 0", water, 200, 120, {"max_depth": 0}), ("water depth 2", water, 203, 117, {"max_depth": 2}),
+            ("synthetic short list", rt.synthetic_scene(n_cubes=200, n_spheres=12), 320, 180, {}),
+            ("synthetic long list", rt.synthetic_scene(n_cubes=1500, n_spheres=12), 320, 180, {}),
+            ("three lights", three, 160, 96, {}), ("no lights", none, 160, 96, {}),
+            ("eye inside the diorama", s, 256, 160, {"camera": _cam((0.2, 1.0, 0.3), (3.0, 0.0, -3.0))}),
+            ("NaN basis", water, 64, 40, {"camera": _cam((0.0, 0.0, 10.0), (0.0, 0.0, 10.0))}),
+            ("band", water, 328, 200, {"y0": 37, "y1": 150})]
+
+
+@pytest.mark.parametrize("cap", [0, 3, 64])
+def test_wavefront_launches_paint_the_same_frame(tuned_ctx, oracle_mod, cap):
+    """RT_TUNE_WAVEFRONT: the plain frame through one launch per ray-tree level over bundles of coherent rays
+    (wf_trace_kernel, wf_combine_kernel) instead of the tile-resident walk.  Every frame equals the debug variant's
+    (one wave per tile walks the whole tree) and the oracle's, bit for bit; with the item capacity cut to a few
+    bundles (RT_TUNE_WAVEFRONT_CAP) most tiles overflow and are rendered again by render_kernel from the redo
+    list, with the same result.  Repeated launches reuse the buffers (stamps tell stale items apart)."""
+    ctx = tuned_ctx
+    ctx.set_tuning(rt.RT_TUNE_WAVEFRONT, 1)
+    ctx.set_tuning(rt.RT_TUNE_WAVEFRONT_CAP, cap)
+    for name, sc, w, h, kw in _wavefront_cases():
+        f, gfb, gpl, ofb, opl, ocnt = _both(ctx, oracle_mod, sc, w, h, **kw)   # _both: plain (wavefront) == debug
+        assert_parity(gfb, gpl, ofb, opl, f"wavefront cap {cap}: {name}")
+        for _ in range(2):
+            got = ctx.render(f)
+            assert np.array_equal(got, gfb), (name, int((got != gfb).sum()))
+
+
+def test_wavefront_random_scenes(tuned_ctx, oracle_mod, default_scene):
+    ctx = tuned_ctx
+    ctx.set_tuning(rt.RT_TUNE_WAVEFRONT, 1)
+    for seed in range(100, 124):
+        sc, label = random_scene(rt, default_scene, seed)
+        f, gfb, gpl, ofb, opl, ocnt = _both(ctx, oracle_mod, sc, 96, 64)
+        assert_parity(gfb, gpl, ofb, opl, "wavefront " + label)
+
+
+def test_wavefront_parts_and_async(tuned_ctx, water_scene):
+    """The wavefront launches behind rt_render_device_part: every part of 2/3-way splits, frames queued back to
+    back on one stream with a moving camera and changing sizes, equal the tile walk's frames."""
+    import torch
+    ctx = tuned_ctx
+    ctx.upload(water_scene)
+    cams = [rt.rotate_cam(water_scene.camera, 0.3 * k, 0.05 * k) for k in range(5)]
+    sizes = [(480, 272), (480, 272), (320, 200), (328, 203), (480, 272)]
+    frames = [water_scene.frame(w, h, camera=c) for (w, h), c in zip(sizes, cams)]
+    ctx.set_tuning(rt.RT_TUNE_WAVEFRONT, 0)
+    want = [ctx.render(f) for f in frames]
+    ctx.set_tuning(rt.RT_TUNE_WAVEFRONT, 1)
+    outs = [torch.zeros((f.height, f.width), dtype=torch.int32, device="cuda") for f in frames]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for f, o in zip(frames, outs):
+            ctx.render_device(f, o.data_ptr())
+    ctx.sync()
+    for f, o, wnt in zip(frames, outs, want):
+        got = o.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, wnt), (f.width, f.height, int((got != wnt).sum()))
+    f = frames[1]
+    for n in (2, 3):
+        for part in range(n):
+            rows = rt.part_rows(f.y1 - f.y0, n, part)
+            po = torch.zeros((rows, f.width), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ctx.render_device(f, po.data_ptr(), n_parts=n, part=part)
+            ctx.sync()
+            idx = rt.part_row_indices(f.y1 - f.y0, n, part)
+            assert np.array_equal(po.cpu().numpy().view(np.uint32), want[1][idx]), (n, part)
+
+
 def test_tuning_keys_are_validated(gpu_ctx):
-    for key, bad in ((rt.RT_TUNE_HEAVY_SYNC, 2), (rt.RT_TUNE_HEAVY_SPIN_LIMIT, -1), (rt.RT_TUNE_HEAVY_SPIN_LIMIT, 0.5), (rt.RT_TUNE_HEAVY_CLASS, 9), (rt.RT_TUNE_HEAVY_CLASS, -2), (rt.RT_TUNE_HEAVY_CLASS, 2.5), (rt.RT_TUNE_COHERENT_SCALE, -1.0), (rt.RT_TUNE_SHADOW_LIST, 2), (rt.RT_TUNE_DARK_KERNEL, 0.5), (rt.RT_TUNE_FILL_MEMSET, -1), (99, 0)):
+    for key, bad in ((rt.RT_TUNE_HEAVY_SYNC, 2), (rt.RT_TUNE_HEAVY_SPIN_LIMIT, -1), (rt.RT_TUNE_HEAVY_SPIN_LIMIT, 0.5), (rt.RT_TUNE_WAVEFRONT, 2), (rt.RT_TUNE_WAVEFRONT_CAP, -1), (rt.RT_TUNE_HEAVY_CLASS, 9), (rt.RT_TUNE_HEAVY_CLASS, -2), (rt.RT_TUNE_HEAVY_CLASS, 2.5), (rt.RT_TUNE_COHERENT_SCALE, -1.0), (rt.RT_TUNE_SHADOW_LIST, 2), (rt.RT_TUNE_DARK_KERNEL, 0.5), (rt.RT_TUNE_FILL_MEMSET, -1), (99, 0)):
         with pytest.raises(rt.RtError) as e:
             gpu_ctx.set_tuning(key, bad)
         assert e.value.code == rt._ffi.RT_ERR_INVALID_ARG
