@@ -19,6 +19,7 @@ pub const RT_TUNE_HEAVY_SYNC: c_int = 7;
 pub const RT_TUNE_HEAVY_SPIN_LIMIT: c_int = 8;
 pub const RT_TUNE_WAVEFRONT: c_int = 9;
 pub const RT_TUNE_WAVEFRONT_CAP: c_int = 10;
+pub const RT_TUNE_CULL_REFINE: c_int = 11;
 pub const RT_MAX_DEPTH: u32 = 3; // src/render.rs:83
 pub const RT_MAX_LIGHTS: u32 = 16;
 pub const RT_TEXTURE_NONE: i32 = -1; // `texture: None`, src/material.rs:6

@@ -223,6 +223,11 @@ typedef enum rt_tuning {
     RT_TUNE_WAVEFRONT_CAP = 10, /* items (ray bundles) per deeper level that the wavefront buffers hold; 0 (default) = from
                                    the frame size.  Tiles whose bundles do not fit are rendered by the tile-resident
                                    kernel instead, so tests lower it to force that path.  Next render call            */
+    RT_TUNE_CULL_REFINE = 11,   /* -1 (default, automatic), 0 or 1: the plain short-list kernel without / with the cull
+                                   refinement (the box form of the wave-level cull applied where the one-radius form
+                                   leaves 20 candidates or more).  Automatic: on for launches of at most 65536 tiles
+                                   and for scenes whose kernel carries the dark-material test.  Results do not
+                                   depend on it.  Next render call                                            */
     RT_TUNE_BVH_DEPTH_LIMIT = 5 /* deepest BVH the per-lane walk takes (1..28, default 28 = the walk's stack);
                                    a deeper tree sends every wave through the chunk traversal.  28 levels
                                    cannot be exceeded by a real list, so tests lower it.  Next rt_scene_upload */
@@ -382,8 +387,9 @@ int rt_set_tuning(rt_ctx* ctx, int key, double value);
 int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t* out_mismatches, uint64_t* out_cases);
 
 /* Name of the render kernel instantiation that rt_render / rt_render_device launch for the uploaded scene,
- *  e.g. "render_kernel<false,false,false,false>" (template arguments: debug planes, counters, long cube list,
- * dark-material test), as it appears in a rocprofv3 kernel trace; with RT_TUNE_HEAVY_CLASS in effect
+ *  e.g. "render_kernel<false,false,0,false>" (template arguments: debug planes, counters, cube list kind - 0 short,
+ * 1 long, 2 short with the cull refinement, as chosen by the context's last plain launch -, dark-material test), as it
+ * appears in a rocprofv3 kernel trace (there with spaces after the commas); with RT_TUNE_HEAVY_CLASS in effect
  * render_heavy_kernel<long list, dark-material test> runs beside it.  No reference counterpart. */
 const char* rt_kernel_name(const rt_ctx* ctx);
 

@@ -36,6 +36,7 @@ RT_TUNE_HEAVY_SYNC = 7
 RT_TUNE_HEAVY_SPIN_LIMIT = 8
 RT_TUNE_WAVEFRONT = 9
 RT_TUNE_WAVEFRONT_CAP = 10
+RT_TUNE_CULL_REFINE = 11
 
 
 class Vec3(C.Structure):

@@ -234,7 +234,7 @@ class Context:
     # the library's defaults; a test session may override entries (tests/conftest.py) to soak a path
     DEFAULT_TUNING = {_ffi.RT_TUNE_COHERENT_SCALE: 1.0, _ffi.RT_TUNE_SHADOW_LIST: -1, _ffi.RT_TUNE_DARK_KERNEL: -1,
                       _ffi.RT_TUNE_FILL_MEMSET: 0, _ffi.RT_TUNE_BVH_DEPTH_LIMIT: 28, _ffi.RT_TUNE_HEAVY_CLASS: -1, _ffi.RT_TUNE_HEAVY_SYNC: -1,
-                      _ffi.RT_TUNE_HEAVY_SPIN_LIMIT: 0, _ffi.RT_TUNE_WAVEFRONT: -1, _ffi.RT_TUNE_WAVEFRONT_CAP: 0}
+                      _ffi.RT_TUNE_HEAVY_SPIN_LIMIT: 0, _ffi.RT_TUNE_WAVEFRONT: -1, _ffi.RT_TUNE_WAVEFRONT_CAP: 0, _ffi.RT_TUNE_CULL_REFINE: -1}
 
     def reset_tuning(self):
         for key, value in self.DEFAULT_TUNING.items():

@@ -166,6 +166,9 @@ struct Params {
     // flight: 1.23 -> 0.94 ms)
     uint32_t bvh_levels;
     float split_thr;  // heavy tiles: a wave whose cull inflation exceeds this is walked bundle by bundle (cube_query, SPLIT)
+    // 1: the plain short-list kernel with the cull refinement (render_kernel<.., 2, ..>): launches that are bound by their
+    // slowest tiles - small frames, the parts of an N-GPU split, scenes with deep ray trees.  Host-side only.
+    uint32_t refine;
     uint32_t heavy_spin_limit;  // heavy_join: polls before it gives up (0: 2^24; 1: report at once, RT_TUNE_HEAVY_SPIN_LIMIT)
 };
 constexpr uint32_t kHeavyCap = 1024;       // heavy tiles per launch; the rest stay with render_kernel

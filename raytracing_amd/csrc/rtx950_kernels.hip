@@ -30,7 +30,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "rtx950_device.h"
+
+
 
 namespace rtx950 {
 namespace {
@@ -856,7 +860,8 @@ DEV void cube_candidate(const Params& P, const RayPre& q, bool active, bool any_
 }
 
 // One pass over a short cube list (at most kSmallChunks chunks of 64, in list order) for the whole wave.
-template <int MODE, typename CP>
+constexpr uint32_t kRefineMin = 20u;  // REFINE: candidates of a chunk from which on the box form of the cull is applied as well (12..32 measured equal)
+template <int MODE, typename CP, bool REFINE>
 DEV void cube_query_small(const Params& P, const RayPre& q, const CP& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
     const uint32_t n = P.n_cubes;
@@ -876,6 +881,17 @@ DEV void cube_query_small(const Params& P, const RayPre& q, const CP& cp, bool a
         if constexpr (MODE == Q_SHADOW) ids = P.cube_id[base + lane];
         unsigned long long M = wave_ballot(cull_test(rec, cp) && (base + lane < n));
         st.ev_cull += (base + lane < n) ? 1u : 0u;
+        // The one-radius cull is loose for a fan of rays (shadow rays towards a light close to the surface, a tile
+        // across two faces): where it leaves many candidates, the box form of the cull (cull_pre_g: six sweeps
+        // instead of one) is worth its price and is applied to the same records.  Its values die here: the candidate
+        // loop below sees a smaller mask and nothing else.
+        if constexpr (REFINE && !std::is_same<CP, CullPreG>::value) {
+            if ((uint32_t)__builtin_popcountll(M) >= kRefineMin && !cp.all) {
+                const CullPreG cg = cull_pre_g(active, o, d, q.wild, P.bound_max, P.origin_bound);
+                M &= wave_ballot(cull_test(rec, cg));
+                st.ev_cull += (base + lane < n) ? 1u : 0u;
+            }
+        }
         PROF_MARK(PH_CULL);
         while (M != 0ull) {
             const uint32_t b = (uint32_t)__builtin_ctzll(M);
@@ -1124,18 +1140,19 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
     }
 }
 
-// LARGE (a kernel template parameter chosen by the length of the cube list) keeps the long-list code out
-// of the kernel that renders short lists: compiled in, it cost the 97-cube benchmark scene 6 %.
-template <int MODE, bool LARGE, uint32_t WAVES, typename CP>
+// LARGE (a kernel template parameter chosen by the length of the cube list: 0 short, 1 long) keeps the long-list
+// code out of the kernel that renders short lists: compiled in, it cost the 97-cube benchmark scene 6 %.  LARGE == 2:
+// a short list with the cull refinement of cube_query_small (kRefineMin), chosen per launch (Params::refine).
+template <int MODE, int LARGE, uint32_t WAVES, typename CP>
 DEV void cube_query_run(const Params& P, const RayPre& q, const CP& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
-    if constexpr (LARGE) {
+    if constexpr (LARGE == 1) {
         // how much the wave's spread inflates every cube in cull_test, against the cubes' own size (wave-uniform)
         const bool coherent = cp.all || !(__builtin_fmaf(2.0f * P.bound_max, cp.dr, cp.wr_raw) > P.coherent_thr);
         if (coherent) cube_query_large<MODE, CP>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
         else cube_query_bvh<MODE, WAVES>(P, q, active, o, d, impact_id, st PROF_PASS);
     } else {
-        cube_query_small<MODE, CP>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+        cube_query_small<MODE, CP, LARGE == 2>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
     }
 }
 
@@ -1147,7 +1164,7 @@ DEV void cube_query_run(const Params& P, const RayPre& q, const CP& cp, bool act
 // key by key, each bundle with its own bound (at most kMaxBundles passes, the last takes all the rest).
 // The folds are per lane, so the order and grouping of the passes change no result.
 constexpr uint32_t kMaxBundles = 3u;
-template <int MODE, bool LARGE, bool SPLIT = false>
+template <int MODE, int LARGE, bool SPLIT = false>
 DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st, uint32_t key PROF_ARG)
 {
     if (P.n_cubes == 0u) return;
@@ -1237,7 +1254,7 @@ DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_
 
 // ---------------------------------------------------------------- nearest hit (render.rs:87-101)
 // `pass` is wave-uniform: PASS_SPHERES walks the sphere list, PASS_CUBES the cube list.
-template <bool COUNT, bool LARGE, bool SPLIT = false>
+template <bool COUNT, int LARGE, bool SPLIT = false>
 DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3 d, bool& div_ok, Counters& cnt, uint32_t key PROF_ARG)
 {
     uint32_t best_idx = kNoHit;
@@ -1282,7 +1299,7 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
 // ---------------------------------------------------------------- shadow (render.rs:44-70)
 // First object in array order, among those whose id differs from the impact object's
 // (render.rs:113), whose ray_intersect returns Some.  Not the nearest one.
-template <bool COUNT, bool LARGE, bool SPLIT = false>
+template <bool COUNT, int LARGE, bool SPLIT = false>
 DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V3 light_pos, V3 dir, uint32_t impact_id, uint32_t& blocker, Counters& cnt, uint32_t key PROF_ARG)
 {
     // dir = normalize(light_pos - origin) (render.rs:46), the caller's light_dir: the same expression
@@ -1474,7 +1491,7 @@ DEV uint32_t mail_collect(const Mailbox& mb, uint32_t depth)
 // One iteration of the light fold of cast_ray (render.rs:104-152, :221-224 without the children): the term
 // (diffuse + specular) * (1 - reflectivity - transparency) of light `li` for the wave's hit points.  `lit`:
 // lanes that cast the shadow ray (a hit whose direct light is not exactly black, see trace_tree).
-template <bool DBG, bool COUNT, bool LARGE, bool SPLIT = false>
+template <bool DBG, bool COUNT, int LARGE, bool SPLIT = false>
 DEV Col light_term(const Params& P, uint32_t pass, uint32_t li, bool lit, bool hit_any, V3 hit_p, V3 hit_n, uint32_t hit_id, V3 view_dir, Col tx_a,
                    float m_specular, float m_albedo1, float k_ds, float ambient, uint32_t& h, Counters& cnt, uint32_t key PROF_ARG)
 {
@@ -1521,7 +1538,7 @@ DEV Col light_term(const Params& P, uint32_t pass, uint32_t li, bool lit, bool h
 // 64 primary rays: returns the packed colour, the primary hit index and the tree hash per lane.
 // ASYNC (render_heavy_kernel's tracer, plain variant only): the light fold of a node is posted to the
 // workgroup's shader waves (`mb`) and its sum collected when the node is finished.
-template <bool DBG, bool COUNT, bool LARGE, bool DARK, bool ASYNC = false, bool SPLIT = ASYNC>
+template <bool DBG, bool COUNT, int LARGE, bool DARK, bool ASYNC = false, bool SPLIT = ASYNC>
 DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d, float ambient, uint32_t* stk, uint32_t& hash, uint32_t& hit_idx,
                         Totals& tot, const Mailbox& mb PROF_ARG)
 {
@@ -1843,8 +1860,8 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
 #ifndef RTX_WAVES_PER_EU_LARGE
 #define RTX_WAVES_PER_EU_LARGE 3  // long lists: per-lane BVH walks want the registers more than the fourth wave (168 instead of 128)
 #endif
-template <bool DBG, bool COUNT, bool LARGE, bool DARK = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU, LARGE ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU))) void render_kernel(const Params P)
+template <bool DBG, bool COUNT, int LARGE, bool DARK = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU, LARGE == 1 ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU))) void render_kernel(const Params P)
 {
     __shared__ uint32_t stk[kStackDepth * frame_words<DBG>() * 64];
     const uint32_t lane = threadIdx.x & 63u;
@@ -2007,7 +2024,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE ? RTX_
 // waves as tracer and shaders (see "heavy tiles" above).  Every pixel is computed by trace_tree, as in
 // render_kernel.  The list was written by the previous launch's build_queue, for whatever camera that launch
 // had: an entry only says "trace this tile", so the cube pass is never skipped here.
-template <bool LARGE, bool DARK, bool ASYNC>
+template <int LARGE, bool DARK, bool ASYNC>
 DEV void plain_tile(const Params& P, uint32_t entry, uint32_t* stk, const Mailbox& mb, uint32_t cost_scale)
 {
     const unsigned long long t_start = __builtin_readcyclecounter();
@@ -2062,7 +2079,7 @@ DEV void plain_tile(const Params& P, uint32_t entry, uint32_t* stk, const Mailbo
 }
 
 // A shader wave's part of one heavy item: serve the nodes the tracer posts until it reports the item done.
-template <bool LARGE>
+template <int LARGE>
 DEV void shader_serve(const Params& P, const Mailbox& mb, uint32_t w, uint32_t items_target)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -2119,7 +2136,7 @@ constexpr uint32_t kHeavyCostScale = 3u;
 #ifndef RTX_HEAVY_WAVES_PER_EU
 #define RTX_HEAVY_WAVES_PER_EU 2  // 256 registers, nothing spilled on the critical path (1080p frame 0.090 -> 0.080 ms against 4)
 #endif
-template <bool LARGE, bool DARK>
+template <int LARGE, bool DARK>
 __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(RTX_HEAVY_WAVES_PER_EU, RTX_HEAVY_WAVES_PER_EU))) void render_heavy_kernel(const Params P)
 {
     constexpr uint32_t kFrame = kStackDepth * frame_words<false, true>() * 64;
@@ -2240,7 +2257,7 @@ struct WfNode {
 
 // One node of cast_ray for the wave's rays: render.rs:87-152 and the child rays of :154-193 (trace_tree's node
 // code without the tree walk around it).
-template <bool LARGE, bool DARK>
+template <int LARGE, bool DARK>
 DEV WfNode wf_node(const Params& P, uint32_t pass, bool act, V3 o, V3 d, float ambient PROF_ARG)
 {
     WfNode r;
@@ -2376,8 +2393,8 @@ DEV void wf_emit(const Params& P, const WfParams& W, uint32_t level, uint32_t it
     n_children = want;
 }
 
-template <bool PRIMARY, bool LARGE, bool DARK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU, LARGE ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU))) void wf_trace_kernel(const Params P, const WfParams W)
+template <bool PRIMARY, int LARGE, bool DARK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU, LARGE == 1 ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU))) void wf_trace_kernel(const Params P, const WfParams W)
 {
     const uint32_t lane = threadIdx.x & 63u;
     PROF_DECL
@@ -2735,11 +2752,13 @@ int launch_render(const Params& p, int variant, void* stream, uint32_t max_workg
         break;
     default:
         if (p.dark_materials != 0u) {
-            if (large) hipLaunchKernelGGL((render_kernel<false, false, true, true>), grid, block, lds, s, p);
-            else hipLaunchKernelGGL((render_kernel<false, false, false, true>), grid, block, lds, s, p);
+            if (large) hipLaunchKernelGGL((render_kernel<false, false, 1, true>), grid, block, lds, s, p);
+            else if (p.refine != 0u) hipLaunchKernelGGL((render_kernel<false, false, 2, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((render_kernel<false, false, 0, true>), grid, block, lds, s, p);
         } else {
-            if (large) hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, lds, s, p);
-            else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, lds, s, p);
+            if (large) hipLaunchKernelGGL((render_kernel<false, false, 1>), grid, block, lds, s, p);
+            else if (p.refine != 0u) hipLaunchKernelGGL((render_kernel<false, false, 2>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((render_kernel<false, false, 0>), grid, block, lds, s, p);
         }
         break;
     }
@@ -2762,11 +2781,11 @@ int launch_wf_trace(const Params& p, const WfParams& w, void* stream, uint32_t m
     const uint32_t lds = large ? p.bvh_levels * 256u : 0u;
 #define RTX_WF_LAUNCH(PRIM, LG, DK) hipLaunchKernelGGL((wf_trace_kernel<PRIM, LG, DK>), grid, block, lds, s, p, w)
     if (primary) {
-        if (large) { if (dark) RTX_WF_LAUNCH(true, true, true); else RTX_WF_LAUNCH(true, true, false); }
-        else { if (dark) RTX_WF_LAUNCH(true, false, true); else RTX_WF_LAUNCH(true, false, false); }
+        if (large) { if (dark) RTX_WF_LAUNCH(true, 1, true); else RTX_WF_LAUNCH(true, 1, false); }
+        else { if (dark) RTX_WF_LAUNCH(true, 2, true); else RTX_WF_LAUNCH(true, 2, false); }  // short lists: with the cull refinement
     } else {
-        if (large) { if (dark) RTX_WF_LAUNCH(false, true, true); else RTX_WF_LAUNCH(false, true, false); }
-        else { if (dark) RTX_WF_LAUNCH(false, false, true); else RTX_WF_LAUNCH(false, false, false); }
+        if (large) { if (dark) RTX_WF_LAUNCH(false, 1, true); else RTX_WF_LAUNCH(false, 1, false); }
+        else { if (dark) RTX_WF_LAUNCH(false, 2, true); else RTX_WF_LAUNCH(false, 2, false); }
     }
 #undef RTX_WF_LAUNCH
     return (int)hipGetLastError();

@@ -692,6 +692,32 @@ def test_side_kernel_moving_camera_empty_and_full_lists():
             c.close()
 
 
+@pytest.mark.parametrize("refine", [0, 1])
+def test_cull_refinement_forced(tuned_ctx, oracle_mod, default_scene, water_scene, refine):
+    """RT_TUNE_CULL_REFINE: the plain short-list kernel without / with the cull refinement (the box form of the
+    wave-level cull applied to chunks where the one-radius form leaves 20 candidates or more; automatic mode turns
+    it on for small launches and dark-material scenes).  Either kernel paints the debug variant's frame (which has
+    no refinement) and the oracle's: the diorama from four sides, the water variant, a dense random scene, 16 lights."""
+    ctx = tuned_ctx
+    ctx.set_tuning(rt.RT_TUNE_CULL_REFINE, refine)
+    s = default_scene
+    lights16 = [rt.Light(rt.Vec3(-8.0 + k, 6.0 + 0.5 * k, 9.0 - 1.3 * k), 0x102030 * (k % 7 + 1) & 0xFFFFFF, 0.05 + 0.07 * k) for k in range(16)]
+    many = rt.make_scene(list(s.cubes), [], list(s.materials), lights16, s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
+    cases = [(s, 480, 270, {}), (water_scene, 480, 270, {}), (many, 160, 96, {}), (rt.synthetic_scene(n_cubes=240, n_spheres=6), 320, 180, {})]
+    cam = s.camera
+    for k in range(3):
+        cam = rt.rotate_cam(cam, 1.3, 0.1)
+        cases.append((s, 320, 200, {"camera": cam}))
+    for sc, w, h, kw in cases:
+        f, gfb, gpl, ofb, opl, ocnt = _both(ctx, oracle_mod, sc, w, h, **kw)
+        assert_parity(gfb, gpl, ofb, opl, f"cull refinement {refine}: {sc.name} {w}x{h}")
+    assert ctx.kernel_name() == f"render_kernel<false,false,{2 if refine else 0},false>"
+    for seed in range(300, 312):
+        sc, label = random_scene(rt, default_scene, seed, 250)
+        f, gfb, gpl, ofb, opl, ocnt = _both(ctx, oracle_mod, sc, 96, 64)
+        assert_parity(gfb, gpl, ofb, opl, f"cull refinement {refine}: " + label)
+
+
 def _wavefront_cases():
     s = rt.default_scene()
     water = rt.default_scene(with_water=True)
@@ -769,7 +795,7 @@ def test_wavefront_parts_and_async(tuned_ctx, water_scene):
 
 
 def test_tuning_keys_are_validated(gpu_ctx):
-    for key, bad in ((rt.RT_TUNE_HEAVY_SYNC, 2), (rt.RT_TUNE_HEAVY_SPIN_LIMIT, -1), (rt.RT_TUNE_HEAVY_SPIN_LIMIT, 0.5), (rt.RT_TUNE_WAVEFRONT, 2), (rt.RT_TUNE_WAVEFRONT_CAP, -1), (rt.RT_TUNE_HEAVY_CLASS, 9), (rt.RT_TUNE_HEAVY_CLASS, -2), (rt.RT_TUNE_HEAVY_CLASS, 2.5), (rt.RT_TUNE_COHERENT_SCALE, -1.0), (rt.RT_TUNE_SHADOW_LIST, 2), (rt.RT_TUNE_DARK_KERNEL, 0.5), (rt.RT_TUNE_FILL_MEMSET, -1), (99, 0)):
+    for key, bad in ((rt.RT_TUNE_HEAVY_SYNC, 2), (rt.RT_TUNE_HEAVY_SPIN_LIMIT, -1), (rt.RT_TUNE_HEAVY_SPIN_LIMIT, 0.5), (rt.RT_TUNE_WAVEFRONT, 2), (rt.RT_TUNE_CULL_REFINE, 3), (rt.RT_TUNE_WAVEFRONT_CAP, -1), (rt.RT_TUNE_HEAVY_CLASS, 9), (rt.RT_TUNE_HEAVY_CLASS, -2), (rt.RT_TUNE_HEAVY_CLASS, 2.5), (rt.RT_TUNE_COHERENT_SCALE, -1.0), (rt.RT_TUNE_SHADOW_LIST, 2), (rt.RT_TUNE_DARK_KERNEL, 0.5), (rt.RT_TUNE_FILL_MEMSET, -1), (99, 0)):
         with pytest.raises(rt.RtError) as e:
             gpu_ctx.set_tuning(key, bad)
         assert e.value.code == rt._ffi.RT_ERR_INVALID_ARG
