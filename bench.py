@@ -172,7 +172,9 @@ def main():
                     help="profiling runs (tools/profile_workloads.sh): only run-in, warm-up, the timed region and the counting launch; "
                          "no CPU baseline and none of the side measurements, so that a rocprofv3 trace of the command holds the timed "
                          "launches and nothing else of the render kernel")
-    ap.add_argument("--extra", action="store_true", help="also time the other Minecraft workloads (N=1 only, untimed region)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip config.extra: the metric's other sizes and scenes (1080p, 4K with water, the 10k-cube world, the 8K orbit), "
+                         "measured after the timed region at N = 1 (about 20 s)")
     args = ap.parse_args()
 
     import torch
@@ -363,7 +365,9 @@ def main():
         achieved_tf = flops_exec / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         prof = profile_entry(args.workload, kernel)
         result = {
-            "metric": "Mrays/s (primary+shadow+secondary, unique rays)",
+            "metric": "Mrays/s (primary+shadow+secondary; unique rays ANSWERED per second: a ray = one nearest-hit or shadow query of the "
+                      "reference's ray tree, SURVEY 8d, whether the kernel traverses the object list for it or proves the answer; "
+                      "config.mrays_per_s_traced counts only the queries the kernel executes)",
             "value": rays_uniq * args.steps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -383,6 +387,9 @@ def main():
                              else ("whole frame on one GPU" + (f", {inflight} frames in flight" if inflight > 1 else "")),
                 "rays_per_frame_unique": rays_uniq, "rays_per_frame_reference": rays_ref,
                 "mrays_per_s_reference_accounting": rays_ref * args.steps / elapsed / 1e6,
+                # queries the kernel EXECUTES per frame, per lane (nearest hit, exact re-run, shadow): the sphere pass over an empty
+                # list and the tiles classified as sky are answered without one
+                "traced_rays_per_frame": int(total_ex.queries), "mrays_per_s_traced": total_ex.queries * args.steps / elapsed / 1e6,
                 "cube_tests_per_frame": int(total.cube_tests), "sphere_tests_per_frame": int(total.sphere_tests),
                 "kernel_ms_per_rank": kern_all, "frames_in_flight": inflight,
             },
@@ -456,14 +463,14 @@ def main():
             if ctx.debug_status() != 0:
                 print("bench.py: a side-kernel wait gave up (rt_debug_status)", file=sys.stderr)
                 sys.exit(3)
-            result["config"]["one_frame_in_flight"] = {"ms_per_step": min(dt, dt_on) * 1e3, "value": rays_uniq / min(dt, dt_on) / 1e6, "unit": "Mrays/s",
-                                                       "side_kernel": "on" if dt_on < dt else "off",
+            result["config"]["one_frame_in_flight"] = {"ms_per_step": dt * 1e3, "value": rays_uniq / dt / 1e6, "unit": "Mrays/s",
+                                                       "side_kernel": "off (the library's default behind the asynchronous entry points)",
                                                        "ms_per_step_side_kernel_off": dt * 1e3, "ms_per_step_side_kernel_on": dt_on * 1e3,
                                                        "kernel_avg_ms": solo_ms, "kernel_avg_ms_side_kernel_on": solo_on_ms,
                                                        "roofline_frac": (flops_exec / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if solo_ms > 0 else None,
                                                        "note": "--inflight 1 makes this the timed mode; side kernel = rt_set_tuning(RT_TUNE_HEAVY_CLASS, 5): the tiles that were "
                                                                "slowest in the previous launch on three-wave workgroups on a second stream (kernel_avg_ms is render_kernel's alone)"}
-            result["single_frame_latency_ms"] = min(lat_off, lat_on) * 1e3
+            result["single_frame_latency_ms"] = lat_off * 1e3  # the library's default for rt_render_device
             result["config"]["single_frame_latency"] = {"side_kernel_off_ms": lat_off * 1e3, "side_kernel_on_ms": lat_on * 1e3,
                                                         "note": "median of 50 frames, launch to completion with the host waiting"}
             # the first frame after a camera jump: the queue order comes from the previous launch's tile costs, so
@@ -501,29 +508,60 @@ def main():
                                                 "bytes_read_back": H * W * 4, "note": "synchronous like the reference's render(): launches + D2H copy + wait; never `value`"}
             pinned.close()
             ctx.set_grid_limit(grid_limit)
-        if world == 1 and args.extra and not args.lean:
+        if world == 1 and not args.no_extra and not args.lean:
+            # BASELINE.json's metric is quoted "at 1080p/4K" and its configs name four more frames: the same measurement
+            # (frames in flight as above, HIP-event kernel time, executed-work fraction) on each, outside the timed region
             extra = {}
-            for name in ("minecraft_1080p", "minecraft_water_4k"):
+            for name in ("minecraft_1080p", "minecraft_water_4k", "synthetic_4k", "minecraft_8k_orbit"):
                 k2, kw2, w2, h2 = WORKLOADS[name]
                 sc2 = make_scene(rt, k2, kw2)
                 for c in ctxs:
                     c.upload(sc2)
+                    c.set_grid_limit(grid_limit)
                 f2 = sc2.frame(w2, h2)
                 o2 = [torch.zeros((h2, w2), dtype=torch.int32, device=dev) for _ in ctxs]
                 torch.cuda.synchronize(dev)  # torch's fills are not ordered against the library's streams
-                for i in range(2 * len(ctxs)):
-                    ctxs[i % len(ctxs)].render_device(f2, o2[i % len(ctxs)].data_ptr())
+                orbit2 = bool(kw2.get("orbit"))
+                cam2 = [sc2.camera]
+
+                def frames2(n):
+                    for i in range(n):
+                        if orbit2:
+                            cam2[0] = rt.rotate_cam(cam2[0], 3.14159265358979 / 180.0, 0.0)
+                            f2.camera = cam2[0]
+                        ctxs[i % len(ctxs)].render_device(f2, o2[i % len(ctxs)].data_ptr())
+                    for c in ctxs:
+                        c.sync()
+                n_warm, n_timed = (10, 40) if name == "synthetic_4k" else (30, 120)
+                frames2(n_warm)
                 for c in ctxs:
-                    c.sync()
+                    c.enable_timing(4)
+                    c.kernel_time_ms()
+                cam2[0] = sc2.camera
                 t1 = time.perf_counter()
-                for i in range(10 * len(ctxs)):
-                    ctxs[i % len(ctxs)].render_device(f2, o2[i % len(ctxs)].data_ptr())
+                frames2(n_timed)
+                dt = (time.perf_counter() - t1) / n_timed
+                kt2 = [c.kernel_time_ms() for c in ctxs]
                 for c in ctxs:
-                    c.sync()
-                dt = (time.perf_counter() - t1) / (10 * len(ctxs))
-                c2 = ctx.count_rays(f2)
-                extra[name] = {"ms_per_frame": dt * 1e3, "mrays_per_s": c2.rays / dt / 1e6, "rays_per_frame_unique": c2.rays, "frames_in_flight": len(ctxs)}
+                    c.enable_timing(False)
+                kn2 = sum(n for _, n in kt2)
+                kms2 = sum(ms * n for ms, n in kt2) / kn2 if kn2 else 0.0
+                f2.camera = sc2.camera
+                c2, e2 = ctx.count_executed(f2)
+                fl2 = executed_flops(e2)
+                extra[name] = {"width": w2, "height": h2, "n_cubes": sc2.n_cubes, "n_spheres": sc2.n_spheres,
+                               "ms_per_frame": dt * 1e3, "mrays_per_s": c2.rays / dt / 1e6, "mrays_per_s_traced": e2.queries / dt / 1e6,
+                               "rays_per_frame_unique": c2.rays, "frames_in_flight": len(ctxs), "frames_timed": n_timed,
+                               "kernel": ctx.kernel_name(), "kernel_avg_ms": kms2,
+                               "executed_flops_per_launch": fl2,
+                               "roofline_frac": (fl2 / (kms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if kms2 > 0 else None}
+                if orbit2:
+                    extra[name]["note"] = "one degree of yaw per frame (Camera::rotate_cam); rays and executed work counted on the first view"
             result["config"]["extra"] = extra
+            result["config"]["extra_note"] = ("the metric's other frames, measured like the headline (frames in flight, HIP-event kernel time every 4th launch) after "
+                                              "the timed region; executed work is counted by the kernel's counting variant, which has no cull refinement")
+            for c in ctxs:
+                c.upload(scene)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -243,6 +243,63 @@ def test_full_size_properties(gpu_ctx, default_scene):
     assert c.ref_rays >= c.rays and c.shadow_rays == 2 * c.shaded_hits
 
 
+def test_config2_1080p_against_the_oracle(gpu_ctx, oracle_mod, default_scene):
+    """BASELINE.json config 2 at its exact size: the diorama at 1920x1080, depth 3 - debug and plain kernels (the
+    plain one is the cull-refinement variant at this size) against the oracle run here on every pixel: hit planes,
+    ray-tree hashes and colours bit-exact, counters equal (about half a second of host threads)."""
+    f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, default_scene, 1920, 1080)
+    rep = assert_parity(gfb, gpl, ofb, opl, "config 2: 1920x1080")
+    assert rep["exact_fraction"] == 1.0, rep
+    assert gpu_ctx.kernel_name() == "render_kernel<false,false,2,false>"
+    c = gpu_ctx.count_rays(f)
+    assert c.uniq_dict() == ocnt.uniq_dict()
+    assert gfb[1, 0] == 0
+
+
+def test_config3_water_4k_properties(gpu_ctx, water_scene):
+    """BASELINE.json config 3 at its exact size (3840x2160, the water platform: reflection + refraction to depth 3):
+    plain == debug on every pixel, bands == the full frame, the parts of a 3-way split reassemble, the unpainted
+    pixel, counters consistent with the tree shape (every shaded hit casts one shadow ray per light; water pixels
+    have two children)."""
+    import torch
+    gpu_ctx.upload(water_scene)
+    W, H = 3840, 2160
+    f = water_scene.frame(W, H)
+    bufs = [torch.zeros((H, W), dtype=torch.int32, device="cuda") for _ in range(2)]
+    hsh = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.render_device(f, bufs[0].data_ptr())
+    gpu_ctx.render_device(f, bufs[1].data_ptr(), d_tree_hash=hsh.data_ptr())
+    gpu_ctx.sync()
+    assert torch.equal(bufs[0], bufs[1])
+    assert gpu_ctx.kernel_name() == "render_kernel<false,false,2,true>"  # dark-material scene: refinement at any size
+    full = bufs[0].cpu().numpy().view(np.uint32)
+    assert full[1, 0] == 0 and full[0, 0] == water_scene.sky_0rgb
+    for y0, y1 in ((0, 97), (1000, 1100), (2100, 2160)):
+        assert np.array_equal(gpu_ctx.render(water_scene.frame(W, H, y0=y0, y1=y1)), full[y0:y1]), (y0, y1)
+    part = torch.zeros((rt.part_rows(H, 3, 0), W), dtype=torch.int32, device="cuda")
+    for p in range(3):
+        torch.cuda.synchronize()
+        gpu_ctx.render_device(f, part.data_ptr(), n_parts=3, part=p)
+        gpu_ctx.sync()
+        rows = rt.part_rows(H, 3, p)
+        assert np.array_equal(part[:rows].cpu().numpy().view(np.uint32), full[rt.part_row_indices(H, 3, p)]), p
+    c = gpu_ctx.count_rays(f)
+    d = gpu_ctx.count_rays(gpu_ctx.scene.frame(W, H, max_depth=0))
+    assert c.shadow_rays == 2 * c.shaded_hits and c.ref_rays > c.rays > d.rays
+    assert c.nearest_rays > d.nearest_rays == 2 * W * H  # depth 0: one primary ray per pass and pixel
+    # the wavefront launches paint the same frame at this size (deep trees: every level has items)
+    gpu_ctx.set_tuning(rt.RT_TUNE_WAVEFRONT, 1)
+    try:
+        torch.cuda.synchronize()
+        gpu_ctx.render_device(f, bufs[1].data_ptr())
+        gpu_ctx.sync()
+        assert torch.equal(bufs[0], bufs[1])
+        assert all(len(gpu_ctx.wavefront_items(level)) > 0 for level in (1, 2, 3))
+    finally:
+        gpu_ctx.set_tuning(rt.RT_TUNE_WAVEFRONT, -1)
+
+
 def test_error_paths(gpu_ctx, default_scene):
     gpu_ctx.upload(default_scene)
     f = default_scene.frame(64, 48)
