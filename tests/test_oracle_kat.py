@@ -157,6 +157,51 @@ def test_numpy_restatement_agrees_on_hit_indices(oracle_mod, default_scene):
     assert np.array_equal(np_restatement.nearest_cube(default_scene, w, h), planes["hit_cube"])
 
 
+def _np_cases():
+    yield "default 135x90", rt.default_scene(), 135, 90, {}
+    yield "water 120x68", rt.default_scene(with_water=True), 120, 68, {}
+    yield "synthetic 600c/24s 96x54", rt.synthetic_scene(n_cubes=600, n_spheres=24), 96, 54, {}
+    yield "water depth 1", rt.default_scene(with_water=True), 64, 40, {"max_depth": 1}
+    yield "water depth 0", rt.default_scene(with_water=True), 64, 40, {"max_depth": 0}
+    s = rt.default_scene()
+    yield "orbit step", s, 96, 64, {"camera": rt.rotate_cam(s.camera, 0.7, -0.3)}
+    yield "eye inside the diorama", s, 64, 40, {"camera": rt.Camera(rt.Vec3(0.2, 1.0, 0.3), rt.Vec3(3.0, 0.0, -3.0), rt.Vec3(0.0, 1.0, 0.0))}
+    yield "looking away (negative-distance hits)", s, 64, 40, {"camera": rt.Camera(rt.Vec3(0.0, 0.0, 10.0), rt.Vec3(0.0, 0.0, 20.0), rt.Vec3(0.0, 1.0, 0.0))}
+
+
+@pytest.mark.parametrize("name,scene,w,h,kw", list(_np_cases()), ids=[c[0] for c in _np_cases()])
+def test_numpy_restatement_agrees_on_whole_frames(oracle_mod, name, scene, w, h, kw):
+    """The second, independent restatement (tests/np_restatement.py: numpy float32, written from the Rust sources,
+    literal per-light re-casting of secondary rays) against the C oracle in BOTH of its modes: framebuffer and
+    depth-0 hit planes equal in every bit.  Covers what the reference's own tests cannot pin: cast_shadow
+    (render.rs:44-70), the light fold and its u8 operation order (:104-225), reflect/refract (:17-42), the
+    face-origin texel lookup (texture.rs:178-196), Sphere::ray_intersect (sphere.rs:25-56), the sphere/cube merge
+    (render.rs:308-312), the unpainted pixel (:314-323)."""
+    import np_restatement
+    f = scene.frame(w, h, **kw)
+    fb, hc, hs = np_restatement.render_frame(scene, f)
+    O = oracle_mod.OracleScene(scene)
+    for reuse in (False, True):
+        ofb, opl, _, _ = O.render(f, debug=True, reuse_secondary=reuse, threads=4)
+        assert np.array_equal(fb, ofb), (name, reuse, int((fb != ofb).sum()))
+        assert np.array_equal(hc, opl["hit_cube"]) and np.array_equal(hs, opl["hit_sphere"]), (name, reuse)
+    assert fb[1, 0] == 0 or w == 1
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5, 8, 11, 17])
+def test_numpy_restatement_agrees_on_random_scenes(oracle_mod, default_scene, seed):
+    """The fuzz generator of the GPU suite (overlapping cubes, repeated ids, spheres, random reflectivity /
+    transparency / refractive index, up to 4 lights) through both restatements."""
+    import np_restatement
+    from parity import random_scene
+    sc, label = random_scene(rt, default_scene, seed, 60)
+    f = sc.frame(40, 28)
+    fb, hc, hs = np_restatement.render_frame(sc, f)
+    ofb, opl, _, _ = oracle_mod.OracleScene(sc).render(f, debug=True, reuse_secondary=False, threads=4)
+    assert np.array_equal(fb, ofb), (label, int((fb != ofb).sum()))
+    assert np.array_equal(hc, opl["hit_cube"]) and np.array_equal(hs, opl["hit_sphere"]), label
+
+
 def test_golden_frame(oracle_mod, default_scene):
     """tests/golden/minecraft_270x180.npz was produced by tests/make_golden.py from this oracle; it pins the
     oracle against accidental change and gives the GPU tests a fixture that needs no oracle run."""
