@@ -154,6 +154,10 @@ struct rt_ctx {
     uint32_t* d_part = nullptr;
     size_t part_capacity = 0;  // in pixels
     hipEvent_t part_done = nullptr;
+    // rt_gather_bands: what this context knows about reaching GPU `peer_target` from its own GPU (asked once per
+    // target): -1 not asked yet, 1 peer access enabled (a device-to-device copy goes over xGMI directly), 0 no peer
+    // access between the two GPUs (the copy is a hipMemcpyPeerAsync, which the runtime stages)
+    int peer_target = -1, peer_state = -1;
     // tuning / test knobs (rt_set_tuning); the library reads no environment variables
     float tune_coherent_scale = 1.0f;
     int tune_shadow_list = -1, tune_dark_kernel = -1;
@@ -1592,10 +1596,21 @@ int rt_gather_bands(rt_ctx* const* ctxs, uint32_t n_ctx, const uint32_t* const* 
     for (uint32_t g = 0; g < n_ctx; ++g) {
         rt_ctx* c = ctxs[g];
         ENTER_DEVICE(c);
+        bool direct = true;  // the destination is addressable from this context's GPU
         if (c->device != c0->device) {
-            hipError_t pe = hipDeviceEnablePeerAccess(c0->device, 0);
-            if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // sticky-free status: already on
-            else if (pe != hipSuccess) return fail_hip(c0, pe, "hipDeviceEnablePeerAccess");
+            if (c->peer_target != c0->device || c->peer_state < 0) {  // once per (context, destination GPU), not per frame
+                int can = 0;
+                HIP_TRY(c0, hipDeviceCanAccessPeer(&can, c->device, c0->device));
+                c->peer_target = c0->device;
+                c->peer_state = 0;
+                if (can) {
+                    hipError_t pe = hipDeviceEnablePeerAccess(c0->device, 0);
+                    if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // another context of this GPU did it
+                    else if (pe != hipSuccess) return fail_hip(c0, pe, "hipDeviceEnablePeerAccess");
+                    c->peer_state = 1;
+                }
+            }
+            direct = c->peer_state == 1;
         }
         const uint32_t my_blocks = (g < blocks) ? (blocks - g + n_ctx - 1u) / n_ctx : 0u;
         if (my_blocks == 0u) continue;
@@ -1603,12 +1618,21 @@ int rt_gather_bands(rt_ctx* const* ctxs, uint32_t n_ctx, const uint32_t* const* 
         const bool ragged = (rows % kRowBlock != 0u) && ((blocks - 1u) % n_ctx == g);
         const uint32_t full = ragged ? my_blocks - 1u : my_blocks;
         uint32_t* dst = d_band_on_ctx0 + (size_t)g * kRowBlock * width;
-        if (full)
-            HIP_TRY(c0, hipMemcpy2DAsync(dst, block_bytes * n_ctx, d_parts[g], block_bytes, block_bytes, full, hipMemcpyDeviceToDevice, c->stream));
-        if (ragged) {
-            const size_t tail_bytes = (size_t)(rows % kRowBlock) * width * sizeof(uint32_t);
-            HIP_TRY(c0, hipMemcpyAsync(dst + (size_t)full * n_ctx * kRowBlock * width, d_parts[g] + (size_t)full * kRowBlock * width, tail_bytes,
-                                       hipMemcpyDeviceToDevice, c->stream));
+        if (direct) {
+            if (full)
+                HIP_TRY(c0, hipMemcpy2DAsync(dst, block_bytes * n_ctx, d_parts[g], block_bytes, block_bytes, full, hipMemcpyDeviceToDevice, c->stream));
+            if (ragged) {
+                const size_t tail_bytes = (size_t)(rows % kRowBlock) * width * sizeof(uint32_t);
+                HIP_TRY(c0, hipMemcpyAsync(dst + (size_t)full * n_ctx * kRowBlock * width, d_parts[g] + (size_t)full * kRowBlock * width, tail_bytes,
+                                           hipMemcpyDeviceToDevice, c->stream));
+            }
+        } else {
+            // no peer access between the two GPUs: one runtime-staged peer copy per 16-row block (slow, but correct)
+            for (uint32_t k = 0; k < my_blocks; ++k) {
+                const size_t bytes = (ragged && k + 1u == my_blocks) ? (size_t)(rows % kRowBlock) * width * sizeof(uint32_t) : block_bytes;
+                HIP_TRY(c0, hipMemcpyPeerAsync(dst + (size_t)k * n_ctx * kRowBlock * width, c0->device, d_parts[g] + (size_t)k * kRowBlock * width, c->device, bytes,
+                                               c->stream));
+            }
         }
         if (c != c0) moved += (uint64_t)rt_part_rows(rows, n_ctx, g) * width * sizeof(uint32_t);
         if (c->stream != c0->stream) {
