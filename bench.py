@@ -292,6 +292,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issued = time.perf_counter()  # everything is enqueued; the host has not waited yet (unless a queue filled up)
     sync()
     if world > 1:
         dist.barrier()
@@ -392,6 +393,9 @@ def main():
                 "traced_rays_per_frame": int(total_ex.queries), "mrays_per_s_traced": total_ex.queries * args.steps / elapsed / 1e6,
                 "cube_tests_per_frame": int(total.cube_tests), "sphere_tests_per_frame": int(total.sphere_tests),
                 "kernel_ms_per_rank": kern_all, "frames_in_flight": inflight,
+                # host time this rank spent issuing a frame (Python + ctypes + the library's three launches; the library's own
+                # share is 7.7 us per frame, tools/host_issue.cpp); an upper bound when the host ran ahead into a full queue
+                "host_issue_us_per_frame": (t_issued - t0) / args.steps * 1e6,
             },
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

@@ -407,7 +407,8 @@ int rt_debug_tile_costs(rt_ctx* ctx, uint32_t* out, size_t cap, size_t* out_tile
 /* Diagnostic, no counterpart in the reference: the item records (ray bundles, 8 words each: cycles the item took,
  * kind | pass << 1, lane mask low / high, root tile entry, first child, children, launch stamp) that the context's last
  * wavefront frame (RT_TUNE_WAVEFRONT) allocated at ray-tree level `level` (1..3; 0: the root slots, two per tile
- * position).  Copies min(cap_items, items) records after waiting for the stream; *out_items = items allocated. */
+ * position; level 4: nothing is copied and *out_items = the tiles on the frame's redo list).  Copies min(cap_items, items)
+ * records after waiting for the stream; *out_items = items allocated. */
 int rt_debug_wavefront_items(rt_ctx* ctx, uint32_t level, uint32_t* out_words, size_t cap_items, size_t* out_items);
 
 /* Raw HIP stream of the context as an opaque pointer (hipStream_t), for hosts that order their

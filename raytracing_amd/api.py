@@ -292,6 +292,12 @@ class Context:
             self._check(self._lib.rt_debug_wavefront_items(self._ctx, level, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
         return out
 
+    def wavefront_redo_tiles(self) -> int:
+        """Tiles of the last wavefront frame whose items did not fit and that render_kernel traced again."""
+        n = C.c_size_t()
+        self._check(self._lib.rt_debug_wavefront_items(self._ctx, 4, None, 0, C.byref(n)))
+        return n.value
+
     def kernel_name(self) -> str:
         """rt_kernel_name: the render kernel instantiation the uploaded scene selects."""
         return (self._lib.rt_kernel_name(self._ctx) or b"").decode()

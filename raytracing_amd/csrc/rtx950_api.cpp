@@ -1725,11 +1725,17 @@ int rt_debug_tile_costs(rt_ctx* ctx, uint32_t* out, size_t cap, size_t* out_tile
 
 int rt_debug_wavefront_items(rt_ctx* ctx, uint32_t level, uint32_t* out_words, size_t cap_items, size_t* out_items)
 {
-    if (!ctx || !out_items || level >= kWfLevels) return fail(ctx, RT_ERR_INVALID_ARG, "null argument or level > 3");
+    if (!ctx || !out_items || level > kWfLevels) return fail(ctx, RT_ERR_INVALID_ARG, "null argument or level > 4");
     *out_items = 0;
     ENTER_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->wf.base) return RT_OK;
+    if (level == kWfLevels) {  // the redo list's length: tiles that render_kernel traced again
+        uint32_t n = 0;
+        HIP_TRY(ctx, hipMemcpy(&n, ctx->wf.w.header + kWfRedoBase, sizeof(n), hipMemcpyDeviceToHost));
+        *out_items = n;
+        return RT_OK;
+    }
     std::vector<WfItem> all;
     if (level == 0u) {
         all.resize(ctx->wf.w.cap[0]);

@@ -31,6 +31,9 @@
 #include <stdint.h>
 
 #include <type_traits>
+#ifndef RTX_WF_GRID
+#define RTX_WF_GRID 8192u
+#endif
 
 #include "rtx950_device.h"
 
@@ -2773,7 +2776,7 @@ int launch_wf_trace(const Params& p, const WfParams& w, void* stream, uint32_t m
     // deeper levels: the item count is only known on the device; a grid of a few thousand workgroups (a multiple of
     // kWfQueues) strides over the sub-queues
     const uint32_t units = p.n_spheres != 0u ? 2u * tiles : tiles;  // level 0: a work unit per tile and traced pass
-    uint32_t g = primary ? (units < max_workgroups ? units : max_workgroups) : (max_workgroups < 8192u ? max_workgroups : 8192u);
+    uint32_t g = primary ? (units < max_workgroups ? units : max_workgroups) : (max_workgroups < RTX_WF_GRID ? max_workgroups : RTX_WF_GRID);
     if (!primary) g = g < kWfQueues ? kWfQueues : (g / kWfQueues) * kWfQueues;
     dim3 grid(g, 1u, 1u), block(64u, 1u, 1u);
     hipStream_t s = (hipStream_t)stream;
