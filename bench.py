@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--wavefront", type=int, default=-1,
                     help="rt_set_tuning(RT_TUNE_WAVEFRONT) of every context: 1 = one launch per ray-tree level over bundles of coherent "
                          "rays instead of the tile-resident walk, 0 = never, -1 = the library's default")
+    ap.add_argument("--refine", type=int, default=-1, help="rt_set_tuning(RT_TUNE_CULL_REFINE) of every context (-1: the library's choice per launch)")
     ap.add_argument("--lean", action="store_true",
                     help="profiling runs (tools/profile_workloads.sh): only run-in, warm-up, the timed region and the counting launch; "
                          "no CPU baseline and none of the side measurements, so that a rocprofv3 trace of the command holds the timed "
@@ -244,6 +245,7 @@ def main():
         c.set_grid_limit(grid_limit)
         c.set_tuning(rt.RT_TUNE_HEAVY_CLASS, args.heavy_class)
         c.set_tuning(rt.RT_TUNE_WAVEFRONT, args.wavefront)
+        c.set_tuning(rt.RT_TUNE_CULL_REFINE, args.refine)
     pipe = FramePipeline(fg, lambda buf, slot: ctxs[slot].render_device(frame, buf.data_ptr(), n_parts=world, part=rank), streams,
                          time_every=max(1, args.time_every)) if piped else None
 
