@@ -1183,8 +1183,11 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
     // the water platform -14 %) and its code costs the common path 4 % (register allocation): on for launches that are
     // bound by their slowest tiles - at most 65 536 tiles (1080p; the parts of an N-GPU split of a 4K frame) - and for
     // scenes with deep ray trees (a material whose direct light is black: the water platform's kernel variant).
+    // Not together with the side kernel, which takes the slowest tiles anyway: the refinement changes the tiles' one-wave
+    // costs against their three-wave costs, tiles then change sides from frame to frame, and the pair is slower than the
+    // side kernel alone (1080p one frame at a time: 0.072 ms without the refinement, 0.099 with it).
     p.refine = (ctx->base.n_chunks == 0u && (ctx->tune_cull_refine >= 0 ? ctx->tune_cull_refine == 1
-                                              : (launch_tiles <= kAutoHeavyMaxTiles || ctx->base.dark_materials != 0u))) ? 1u : 0u;
+                                              : (!heavy_on && (launch_tiles <= kAutoHeavyMaxTiles || ctx->base.dark_materials != 0u)))) ? 1u : 0u;
     if (variant == kVariantRender) ctx->last_refine = p.refine != 0u;
     if (wavefront) return launch_wavefront(ctx, p);
     if ((rc = launch_timed(ctx, p, variant)) != RT_OK) return rc;
