@@ -247,9 +247,19 @@ def test_config2_1080p_against_the_oracle(gpu_ctx, oracle_mod, default_scene):
     """BASELINE.json config 2 at its exact size: the diorama at 1920x1080, depth 3 - debug and plain kernels (the
     plain one is the cull-refinement variant at this size) against the oracle run here on every pixel: hit planes,
     ray-tree hashes and colours bit-exact, counters equal (about half a second of host threads)."""
+    import torch
     f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, default_scene, 1920, 1080)
     rep = assert_parity(gfb, gpl, ofb, opl, "config 2: 1920x1080")
     assert rep["exact_fraction"] == 1.0, rep
+    # _both's plain frame came from the synchronous rt_render (side kernel for the slowest tiles, no refinement at this
+    # size); the asynchronous entry point takes the cull-refinement variant: the same frame, twice in a row
+    assert gpu_ctx.kernel_name() == "render_kernel<false,false,0,false>"
+    out = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):
+        gpu_ctx.render_device(f, out.data_ptr())
+        gpu_ctx.sync()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), gfb)
     assert gpu_ctx.kernel_name() == "render_kernel<false,false,2,false>"
     c = gpu_ctx.count_rays(f)
     assert c.uniq_dict() == ocnt.uniq_dict()
