@@ -1574,6 +1574,10 @@ int rt_render_device_noalloc(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_out_0rgb, (int)p.sky, npx, ctx->stream));
         p.prefilled = 1u;
     }
+    // the same choice of kernel variant as rt_render_device (no side kernel here)
+    p.refine = (ctx->base.n_chunks == 0u && (ctx->tune_cull_refine >= 0 ? ctx->tune_cull_refine == 1
+                                              : (frame_tiles <= kAutoHeavyMaxTiles || ctx->base.dark_materials != 0u))) ? 1u : 0u;
+    ctx->last_refine = p.refine != 0u;
     if ((rc = listing(ctx, p, kVariantRender)) != RT_OK) return rc;
     hipError_t e = (hipError_t)launch_render(p, kVariantRender, (void*)ctx->stream, ctx->max_workgroups);
     if (e != hipSuccess) return fail_hip(ctx, e, "render kernel launch");
