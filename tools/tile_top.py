@@ -1,0 +1,22 @@
+"""Tile cost distribution (cycles per 8x8 tile, rt_debug_tile_costs) with the cull refinement forced on.  Usage (GPU box): python tools/tile_top.py [1080p|4k] [water]"""
+import sys, numpy as np
+sys.path.insert(0, '/root/repo')
+import raytracing_amd as rt, torch
+W, H = (1920, 1080) if len(sys.argv) < 2 or sys.argv[1] == "1080p" else (3840, 2160)
+water = len(sys.argv) > 2 and sys.argv[2] == "water"
+s = rt.default_scene(with_water=water)
+ctx = rt.Context(0); ctx.upload(s)
+out = torch.zeros((H, W), dtype=torch.int32, device="cuda"); torch.cuda.synchronize()
+f = s.frame(W, H)
+for refine in (1,):
+    ctx.set_tuning(rt.RT_TUNE_CULL_REFINE, refine)
+    for _ in range(20):
+        ctx.render_device(f, out.data_ptr())
+    ctx.sync()
+    c = ctx.tile_costs().astype(np.int64)
+    tx = (W + 7) // 8
+    nz = c[c > 0]
+    print(f"refine {refine}: traced tiles {len(nz)} avg {nz.mean():.0f} p90 {np.percentile(nz,90):.0f} p99 {np.percentile(nz,99):.0f} max {nz.max()} sum {nz.sum()/1e6:.1f}M")
+    top = np.argsort(-c)[:12]
+    print("   top:", [(int(t % tx), int(t // tx), int(c[t])) for t in top])
+    h, e = np.histogram(nz, bins=[0, 8e3, 16e3, 32e3, 64e3, 128e3, 256e3, 512e3, 1e9]); print("   hist", h.tolist())
