@@ -7,6 +7,8 @@
 //   cast_shadow()       src/render.rs:44-70     -> shadow_query (inlined, list order, early exit)
 //   the slowest tiles of a frame                -> render_heavy_kernel (three waves per tile on a second stream:
 //                                                 same functions, same arithmetic; see "heavy tiles")
+//   cast_ray()'s recursion, level by level      -> wf_trace_kernel / wf_combine_kernel (opt-in wavefront path: one launch
+//                                                 per ray-tree level over bundles of coherent rays; same functions)
 //   Cube::ray_intersect src/cube.rs:77-218      -> cull_test (one conservative test per cube for all 64
 //                                                 rays of a wave) + cube_slab_approx (per-ray two-sided
 //                                                 filter, FMA) + cube_exact (IEEE, only where needed)
