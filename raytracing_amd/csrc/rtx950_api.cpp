@@ -582,14 +582,21 @@ int launch_wavefront(rt_ctx* ctx, const Params& p)
     hipError_t e = (hipError_t)launch_wf_trace(p, w, (void*)ctx->stream, ctx->max_workgroups);
     if (e != hipSuccess) return fail_hip(ctx, e, "wavefront level-0 launch");
     // children exist only if some material reflects or refracts, a light is on and the depth limit allows them
-    if (ctx->scene_has_children && p.n_lights != 0u && p.max_depth != 0u) {
+    const bool deeper = ctx->scene_has_children && p.n_lights != 0u && p.max_depth != 0u;
+    if (deeper) {
         for (uint32_t level = 1; level <= p.max_depth; ++level) {
             w.level = level;
             e = (hipError_t)launch_wf_trace(p, w, (void*)ctx->stream, ctx->max_workgroups);
             if (e != hipSuccess) return fail_hip(ctx, e, "wavefront level launch");
         }
+    }
+    // level 0 paints a tile itself only if the tile has one pass and no children: with spheres in the scene every
+    // root waits for the merge of its two passes (render.rs:308-312), children or not
+    if (deeper || p.n_spheres != 0u) {
         e = (hipError_t)launch_wf_combine(p, w, (void*)ctx->stream, ctx->max_workgroups);
         if (e != hipSuccess) return fail_hip(ctx, e, "wavefront combine launch");
+    }
+    if (deeper) {
         Params redo = p;  // the tiles whose items did not fit: render_kernel traces them whole (usually none)
         redo.queue = w.header + kWfRedoBase;
         redo.qsel = 0u;

@@ -791,7 +791,19 @@ def _wavefront_cases():
     lights16 = [rt.Light(rt.Vec3(-8.0 + k, 6.0 + 0.5 * k, 9.0 - 1.3 * k), 0x102030 * (k % 7 + 1) & 0xFFFFFF, 0.05 + 0.07 * k) for k in range(16)]
     three = rt.make_scene(list(s.cubes), [], list(s.materials), lights16[:3], s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
     none = rt.make_scene(list(s.cubes), [], list(s.materials), [], s.camera, s.ambient_light, s.sky_0rgb, s.atlas)
-    return [("diorama", s, 480, 270, {}), ("water", water, 480, 270, {}), ("water depth 1", water, 200, 120, {"max_depth": 1}),
+    syn = rt.synthetic_scene(n_cubes=200, n_spheres=12)
+    matte = []
+    for m in syn.materials:
+        m = rt.Material.from_buffer_copy(m)
+        m.reflectivity = 0.0
+        m.transparency = 0.0
+        matte.append(m)
+    syn_matte = rt.make_scene(list(syn.cubes), list(syn.spheres), matte, list(syn.lights), syn.camera, syn.ambient_light, syn.sky_0rgb, syn.atlas)
+    syn_dark = rt.make_scene(list(syn.cubes), list(syn.spheres), list(syn.materials), [], syn.camera, syn.ambient_light, syn.sky_0rgb, syn.atlas)
+    # two passes (spheres and cubes) whose roots have no children: the merge still has to run
+    flat = [("spheres, depth 0", syn, 200, 120, {"max_depth": 0}), ("spheres, matte materials", syn_matte, 200, 120, {}),
+            ("spheres, no lights", syn_dark, 200, 120, {})]
+    return flat + [("diorama", s, 480, 270, {}), ("water", water, 480, 270, {}), ("water depth 1", water, 200, 120, {"max_depth": 1}),
             ("water depth 0", water, 200, 120, {"max_depth": 0}), ("water depth 2", water, 203, 117, {"max_depth": 2}),
             ("synthetic short list", rt.synthetic_scene(n_cubes=200, n_spheres=12), 320, 180, {}),
             ("synthetic long list", rt.synthetic_scene(n_cubes=1500, n_spheres=12), 320, 180, {}),
