@@ -502,6 +502,10 @@ DEV V3 refract(V3 i, V3 n, float eta_t)
 // vanishing fraction of cases); evaluating in f64 and rounding once reproduces that far more
 // closely than the 1-2 ulp f32 device routine.  Two calls per shaded hit: not a hot spot.
 DEV bool wave_any_early(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// Out of line on purpose.  Inlined, the f64 routine's thirty-five 32-bit halves of polynomial coefficients (f64
+// operands cannot be literals) are hoisted out of every loop into the kernel's prologue and hold 35 of its 128
+// vector registers from the first instruction to the last, for a path that one light iteration in ten takes.
+__attribute__((noinline)) __device__ float pow_f64_rounded(float x, float y) { return (float)pow((double)x, (double)y); }
 DEV float powf_like_libm(float x, float y)
 {
     // exact special cases of powf first (most shaded points have a clamped base of exactly 0):
@@ -529,7 +533,7 @@ DEV float powf_like_libm(float x, float y)
         }
     }
     if (__builtin_amdgcn_ballot_w64(full) != 0ull) {
-        if (full) r = (float)pow((double)x, (double)y);
+        if (full) r = pow_f64_rounded(x, y);
     }
     return r;
 }
@@ -1863,7 +1867,7 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
 #define RTX_WAVES_PER_EU 4
 #endif
 #ifndef RTX_WAVES_PER_EU_LARGE
-#define RTX_WAVES_PER_EU_LARGE 3  // long lists: per-lane BVH walks want the registers more than the fourth wave (168 instead of 128)
+#define RTX_WAVES_PER_EU_LARGE 4  // long lists: 128 registers hold the per-lane BVH walk since pow_f64_rounded is out of line (three waves and 168 before)
 #endif
 template <bool DBG, bool COUNT, int LARGE, bool DARK = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU, LARGE == 1 ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU))) void render_kernel(const Params P)
