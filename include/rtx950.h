@@ -225,10 +225,9 @@ typedef enum rt_tuning {
                                    kernel instead, so tests lower it to force that path.  Next render call            */
     RT_TUNE_CULL_REFINE = 11,   /* -1 (default, automatic), 0 or 1: the plain short-list kernel without / with the cull
                                    refinement (the box form of the wave-level cull applied where the one-radius form
-                                   leaves 20 candidates or more).  Automatic: on for launches of at most 65536 tiles
-                                   and for scenes whose kernel carries the dark-material test, unless the side
-                                   kernel for heavy tiles is in use (it takes the slowest tiles anyway).  Results do not
-                                   depend on it.  Next render call                                            */
+                                   leaves 20 candidates or more).  Automatic: on, unless the side kernel for heavy
+                                   tiles is in use (it takes the slowest tiles anyway).  Results do not depend on
+                                   it.  Next render call                                                      */
     RT_TUNE_BVH_DEPTH_LIMIT = 5 /* deepest BVH the per-lane walk takes (1..28, default 28 = the walk's stack);
                                    a deeper tree sends every wave through the chunk traversal.  28 levels
                                    cannot be exceeded by a real list, so tests lower it.  Next rt_scene_upload */

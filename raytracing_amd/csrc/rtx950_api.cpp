@@ -330,6 +330,17 @@ void fill_frame(const rt_ctx* ctx, const rt_frame* f, Params& p)
         ob += 1.0f;
         p.origin_bound = (ob <= 0x1p20f) ? ob : 0x1p20f;  // NaN -> 2^20
     }
+    // what every wave would compute for itself (Params: "wave-uniform float values"), in the kernels' f32 operations
+    p.width_f = (float)f->width;
+    p.height_f = (float)f->height;
+    p.aspect = p.width_f / p.height_f;
+    p.n_lights_f = (float)f->n_lights;
+    p.cull_slack = 0x1p-17f * (p.bound_max + p.origin_bound + 1.0f);
+    p.sphere_cull_slack = 0x1p-17f * (p.sphere_bound_max + p.origin_bound + 1.0f);
+    {
+        const float t = p.origin_bound + p.sphere_bound_max + 1.0f;
+        p.sphere_grow = 0x1p-17f * t * t;
+    }
     p.ambient = f->ambient_light;
     p.sky = f->sky_0rgb & 0x00FFFFFFu;
     p.max_depth = f->max_depth;
@@ -1048,6 +1059,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     b.tex_w = n_textures ? tex_w : 1u;
     b.tex_h = n_textures ? tex_h : 1u;
     b.sprite = (float)sprite;  // `sprite_size as f32`, texture.rs:179
+    b.sprite_x0 = b.sprite * 0.0f;
+    b.sprite_x2 = b.sprite * 2.0f;
+    b.sprite_x3 = b.sprite * 3.0f;
     b.bound_max = bmax;
     b.fast_ok = fast_ok ? 1u : 0u;
     ctx->has_scene = true;
@@ -1186,15 +1200,14 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
         }
     }
     // The cull refinement (render_kernel<.., 2, ..>, short lists): where the one-radius cull leaves many candidates the
-    // box form of the cull is applied as well.  It shortens the slowest tiles (1080p one frame at a time -10 %, 4K with
-    // the water platform -14 %) and its code costs the common path 4 % (register allocation): on for launches that are
-    // bound by their slowest tiles - at most 65 536 tiles (1080p; the parts of an N-GPU split of a 4K frame) - and for
-    // scenes with deep ray trees (a material whose direct light is black: the water platform's kernel variant).
+    // box form of the cull is applied as well.  It shortens the slowest tiles (1080p one frame at a time -15 %, 4K with
+    // the water platform -14 %, 4K diorama -4 %, 8K -4 %); its code used to cost the common path 4 % in register
+    // allocation and was kept to launches bound by their slowest tiles, until the kernels got 35 registers back
+    // (pow_f64_rounded): now on for every short-list launch.
     // Not together with the side kernel, which takes the slowest tiles anyway: the refinement changes the tiles' one-wave
     // costs against their three-wave costs, tiles then change sides from frame to frame, and the pair is slower than the
     // side kernel alone (1080p one frame at a time: 0.072 ms without the refinement, 0.099 with it).
-    p.refine = (ctx->base.n_chunks == 0u && (ctx->tune_cull_refine >= 0 ? ctx->tune_cull_refine == 1
-                                              : (!heavy_on && (launch_tiles <= kAutoHeavyMaxTiles || ctx->base.dark_materials != 0u)))) ? 1u : 0u;
+    p.refine = (ctx->base.n_chunks == 0u && (ctx->tune_cull_refine >= 0 ? ctx->tune_cull_refine == 1 : !heavy_on)) ? 1u : 0u;
     if (variant == kVariantRender) ctx->last_refine = p.refine != 0u;
     if (wavefront) return launch_wavefront(ctx, p);
     if ((rc = launch_timed(ctx, p, variant)) != RT_OK) return rc;
@@ -1582,8 +1595,7 @@ int rt_render_device_noalloc(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out
         p.prefilled = 1u;
     }
     // the same choice of kernel variant as rt_render_device (no side kernel here)
-    p.refine = (ctx->base.n_chunks == 0u && (ctx->tune_cull_refine >= 0 ? ctx->tune_cull_refine == 1
-                                              : (frame_tiles <= kAutoHeavyMaxTiles || ctx->base.dark_materials != 0u))) ? 1u : 0u;
+    p.refine = (ctx->base.n_chunks == 0u && (ctx->tune_cull_refine >= 0 ? ctx->tune_cull_refine == 1 : true)) ? 1u : 0u;
     ctx->last_refine = p.refine != 0u;
     if ((rc = listing(ctx, p, kVariantRender)) != RT_OK) return rc;
     hipError_t e = (hipError_t)launch_render(p, kVariantRender, (void*)ctx->stream, ctx->max_workgroups);

@@ -170,6 +170,14 @@ struct Params {
     // slowest tiles - small frames, the parts of an N-GPU split, scenes with deep ray trees.  Host-side only.
     uint32_t refine;
     uint32_t heavy_spin_limit;  // heavy_join: polls before it gives up (0: 2^24; 1: report at once, RT_TUNE_HEAVY_SPIN_LIMIT)
+    // ---- wave-uniform float values that the kernels would otherwise compute once per wave and then hold in vector
+    // registers from the first instruction to the last (the scalar unit has no float arithmetic): computed by the
+    // host with the same f32 operations (fill_frame / rt_scene_upload), read through the scalar cache where used
+    float width_f, height_f, aspect;        // (f32) width, (f32) height, width_f / height_f (render.rs:253-257)
+    float n_lights_f;                       // (f32) n_lights (node_finish)
+    float sprite_x0, sprite_x2, sprite_x3;  // sprite * 0.0f, * 2.0f, * 3.0f (texture.rs:178-196)
+    float cull_slack, sphere_cull_slack;    // 2^-17 (bound_max + origin_bound + 1), the cube list's and the sphere list's (cull_pre)
+    float sphere_grow;                      // 2^-17 (origin_bound + sphere_bound_max + 1)^2 (sphere_query)
 };
 constexpr uint32_t kHeavyCap = 1024;       // heavy tiles per launch; the rest stay with render_kernel
 constexpr uint32_t kHeavyTarget = 512;     // classify_tiles raises the class threshold until about this many tiles qualify:

@@ -460,11 +460,11 @@ DEV Col texel_of_face(const Params& P, int tex, int face, float x, float y)
     float ox, oy;
     switch (face) {
     case FACE_TOP: ox = sp; oy = sp; break;
-    case FACE_BOTTOM: ox = sp; oy = sp * 3.0f; break;
-    case FACE_FORWARDS: ox = sp; oy = sp * 0.0f; break;
-    case FACE_BACKWARDS: ox = sp; oy = sp * 2.0f; break;
+    case FACE_BOTTOM: ox = sp; oy = P.sprite_x3; break;
+    case FACE_FORWARDS: ox = sp; oy = P.sprite_x0; break;
+    case FACE_BACKWARDS: ox = sp; oy = P.sprite_x2; break;
     case FACE_LEFT: ox = 0.0f; oy = sp; break;
-    case FACE_RIGHT: ox = sp * 2.0f; oy = sp; break;
+    case FACE_RIGHT: ox = P.sprite_x2; oy = sp; break;
     default: return col_from_hex(0xff00ffu);
     }
     float px = ox + x, py = oy + y;
@@ -627,7 +627,6 @@ struct CullPre {  // wave-uniform
     float wr_raw;               // ... without the slack
     float sxy, syz, szx;        // upper bounds of |d_i| + |d_j|
     float ax, ay, az;           // upper bounds of |d_i|
-    float omax;                 // largest origin coordinate magnitude
     bool all;                   // some active ray is non-finite or huge: keep every cube
 };
 
@@ -663,7 +662,7 @@ DEV void wave_max2(float a, float b, float& out_a, float& out_b)
 
 // origin_bound: an upper bound of every active lane's origin coordinates (Params::origin_bound; lanes
 // beyond it are `wild`), used where the wave's largest origin magnitude used to be reduced.
-DEV CullPre cull_pre(bool active, V3 o, V3 d, bool wild, float bound_max, float origin_bound)
+DEV CullPre cull_pre(bool active, V3 o, V3 d, bool wild, float slack_k)
 {
     CullPre c;
     const unsigned long long am = wave_ballot(active);
@@ -682,18 +681,16 @@ DEV CullPre cull_pre(bool active, V3 o, V3 d, bool wild, float bound_max, float 
     const float wr = __builtin_fmaxf(__builtin_fabsf(wxy - c.wxyc), __builtin_fmaxf(__builtin_fabsf(wyz - c.wyzc), __builtin_fabsf(wzx - c.wzxc)));
     float wrm;
     wave_max2(active ? dr : z, active ? wr : z, c.dr, wrm);
-    const float omax = origin_bound;
     const float ax = __builtin_fabsf(c.dxc) + c.dr, ay = __builtin_fabsf(c.dyc) + c.dr, az = __builtin_fabsf(c.dzc) + c.dr;
     c.sxy = ax + ay; c.syz = ay + az; c.szx = az + ax;
     c.ax = ax; c.ay = ay; c.az = az;
-    // Rounding slack.  Sources (u = 2^-24, B = largest bound magnitude, O = omax, D = ax+ay+az >= |d_c|):
+    // Rounding slack.  Sources (u = 2^-24, B = largest bound magnitude, O = Params::origin_bound, D = ax+ay+az >= |d_c|):
     //   this test's own fma chains and the per-lane moments      <= ~12 u (B + O) D
     //   the reference's rounded t values vs exact arithmetic      <= ~12 u (B + O) D   (see cube_slab_approx)
     // 2^-17 (B + O + 1) max(D, 1) = 128 u (...) covers both several times over.
-    const float slack = 0x1p-17f * (bound_max + omax + 1.0f) * __builtin_fmaxf(ax + ay + az, 1.0f);
+    const float slack = slack_k * __builtin_fmaxf(ax + ay + az, 1.0f);  // slack_k = 2^-17 (B + O + 1): Params::cull_slack / sphere_cull_slack
     c.wr = wrm + slack;
     c.wr_raw = wrm;
-    c.omax = omax;
     return c;
 }
 
@@ -733,7 +730,6 @@ struct CullPreG {  // wave-uniform
     float ax, ay, az;           // upper bounds of |d_i|
     float cx, cy, cz;           // the reference lane's origin: cube centres and moments are taken about it
     float dr, wr_raw;           // largest half widths (traversal choice of long lists, SPLIT trigger)
-    float omax;
     bool all;                   // some active ray is non-finite or huge: keep every cube
 };
 // centre and half width of the active lanes' values of v, as offsets from a reference value
@@ -745,7 +741,7 @@ DEV void wave_box(bool active, float v, float ref, float& centre, float& half)
     centre = ref + 0.5f * (up - dn);
     half = 0.5f * (up + dn);
 }
-DEV CullPreG cull_pre_g(bool active, V3 o, V3 d, bool wild, float bound_max, float origin_bound)
+DEV CullPreG cull_pre_g(bool active, V3 o, V3 d, bool wild, float slack_k)
 {
     CullPreG c;
     const unsigned long long am = wave_ballot(active);
@@ -763,11 +759,10 @@ DEV CullPreG cull_pre_g(bool active, V3 o, V3 d, bool wild, float bound_max, flo
     wave_box(active, wyz, 0.0f, c.wyzc, ryz);
     wave_box(active, wzx, 0.0f, c.wzxc, rzx);
     c.ax = __builtin_fabsf(c.dxc) + c.rdx; c.ay = __builtin_fabsf(c.dyc) + c.rdy; c.az = __builtin_fabsf(c.dzc) + c.rdz;
-    const float slack = 0x1p-17f * (bound_max + origin_bound + 1.0f) * __builtin_fmaxf(c.ax + c.ay + c.az, 1.0f);  // see cull_pre
+    const float slack = slack_k * __builtin_fmaxf(c.ax + c.ay + c.az, 1.0f);  // see cull_pre
     c.rwxy = rxy + slack; c.rwyz = ryz + slack; c.rwzx = rzx + slack;
     c.dr = __builtin_fmaxf(c.rdx, __builtin_fmaxf(c.rdy, c.rdz));
     c.wr_raw = __builtin_fmaxf(rxy, __builtin_fmaxf(ryz, rzx));
-    c.omax = origin_bound;
     return c;
 }
 DEV bool cull_test(f32x4 k, const CullPreG& c)
@@ -896,7 +891,7 @@ DEV void cube_query_small(const Params& P, const RayPre& q, const CP& cp, bool a
         // loop below sees a smaller mask and nothing else.
         if constexpr (REFINE && !std::is_same<CP, CullPreG>::value) {
             if ((uint32_t)__builtin_popcountll(M) >= kRefineMin && !cp.all) {
-                const CullPreG cg = cull_pre_g(active, o, d, q.wild, P.bound_max, P.origin_bound);
+                const CullPreG cg = cull_pre_g(active, o, d, q.wild, P.cull_slack);
                 M &= wave_ballot(cull_test(rec, cg));
                 st.ev_cull += (base + lane < n) ? 1u : 0u;
             }
@@ -1182,7 +1177,7 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
     st.div_ok = q.div_ok;
     if constexpr (SPLIT) {
         // heavy tiles: the general cull (cull_pre_g), and bundle by bundle where that is still loose
-        const CullPreG cp = cull_pre_g(active, o, d, q.wild, P.bound_max, P.origin_bound);
+        const CullPreG cp = cull_pre_g(active, o, d, q.wild, P.cull_slack);
         const unsigned long long am = wave_ballot(active);
         const uint32_t key0 = (uint32_t)__builtin_amdgcn_readlane((int)key, am ? (int)__builtin_ctzll(am) : 0);
         if (!cp.all && (__builtin_fmaf(2.0f * P.bound_max, cp.dr, cp.wr_raw) > P.split_thr) && wave_any(active && key != key0)) {
@@ -1192,7 +1187,7 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
                 if (rm == 0ull) break;
                 const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(rm));
                 const bool sel = rem && ((b + 1u == kMaxBundles) || (key == kb));
-                const CullPreG cpb = cull_pre_g(sel, o, d, q.wild, P.bound_max, P.origin_bound);
+                const CullPreG cpb = cull_pre_g(sel, o, d, q.wild, P.cull_slack);
                 cube_query_run<MODE, LARGE, kWgWaves, CullPreG>(P, q, cpb, sel, o, d, impact_id, st PROF_PASS);
                 rem = rem && !sel;
             }
@@ -1200,7 +1195,7 @@ DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id
         }
         cube_query_run<MODE, LARGE, kWgWaves, CullPreG>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
     } else {
-        const CullPre cp = cull_pre(active, o, d, q.wild, P.bound_max, P.origin_bound);
+        const CullPre cp = cull_pre(active, o, d, q.wild, P.cull_slack);
         cube_query_run<MODE, LARGE, 1u, CullPre>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
     }
 }
@@ -1228,8 +1223,8 @@ DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_
 {
     const uint32_t n = P.n_spheres;
     if (n == 0u) return;
-    const CullPre cp = cull_pre(active, o, d, ray_wild(P, o, d) || (P.sphere_ok == 0u), P.sphere_bound_max, P.origin_bound);
-    const float grow = 0x1p-17f * (cp.omax + P.sphere_bound_max + 1.0f) * (cp.omax + P.sphere_bound_max + 1.0f);
+    const CullPre cp = cull_pre(active, o, d, ray_wild(P, o, d) || (P.sphere_ok == 0u), P.sphere_cull_slack);
+    const float grow = P.sphere_grow;  // 2^-17 (O + B + 1)^2
     const uint32_t lane = threadIdx.x & 63u;
     const f32x4* filt = (const f32x4*)P.sphere_filt;
     bool done = false;
@@ -1404,7 +1399,7 @@ DEV uint32_t node_finish(const Params& P, uint32_t sumf, float k_r, float k_t, u
     const Col sum = col_from_hex(sumf);
     const Col rl = col_mul(col_from_hex(c_refl), k_r);
     const Col rr = col_mul(col_from_hex(c_refr), k_t);
-    const float fl = (float)P.n_lights;
+    const float fl = P.n_lights_f;
     Col lit;
     lit.r = __builtin_fminf(sum.r + fl * rl.r + fl * rr.r, 255.0f);
     lit.g = __builtin_fminf(sum.g + fl * rl.g + fl * rr.g, 255.0f);
@@ -1934,8 +1929,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ?
         }
     }
     if (!painted) {
-        const float width = (float)P.width, height = (float)P.height;
-        const float aspect = width / height;
+        const float width = P.width_f, height = P.height_f;
+        const float aspect = P.aspect;
         const V3 right = v3(P.right[0], P.right[1], P.right[2]);
         const V3 up = v3(P.up[0], P.up[1], P.up[2]);
         const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
@@ -2038,8 +2033,8 @@ DEV void plain_tile(const Params& P, uint32_t entry, uint32_t* stk, const Mailbo
 {
     const unsigned long long t_start = __builtin_readcyclecounter();
     const uint32_t lane = threadIdx.x & 63u;
-    const float width = (float)P.width, height = (float)P.height;
-    const float aspect = width / height;
+    const float width = P.width_f, height = P.height_f;
+    const float aspect = P.aspect;
     const V3 right = v3(P.right[0], P.right[1], P.right[2]);
     const V3 up = v3(P.up[0], P.up[1], P.up[2]);
     const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
@@ -2441,8 +2436,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ?
             uint32_t fc = 0u, nc = 0u;
             if (!skip) {
                 // render.rs:253-263, camera.rs:38-40
-                const float width = (float)P.width, height = (float)P.height;
-                const float aspect = width / height;
+                const float width = P.width_f, height = P.height_f;
+                const float aspect = P.aspect;
                 float sx = (2.0f * (float)x) / width - 1.0f;
                 const float sy = -(2.0f * (float)y) / height + 1.0f;
                 sx = sx * aspect;

@@ -251,8 +251,8 @@ def test_config2_1080p_against_the_oracle(gpu_ctx, oracle_mod, default_scene):
     f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, default_scene, 1920, 1080)
     rep = assert_parity(gfb, gpl, ofb, opl, "config 2: 1920x1080")
     assert rep["exact_fraction"] == 1.0, rep
-    # _both's plain frame came from the synchronous rt_render (side kernel for the slowest tiles, no refinement at this
-    # size); the asynchronous entry point takes the cull-refinement variant: the same frame, twice in a row
+    # _both's plain frame came from the synchronous rt_render (side kernel for the slowest tiles, hence no cull
+    # refinement); the asynchronous entry point takes the cull-refinement variant: the same frame, twice in a row
     assert gpu_ctx.kernel_name() == "render_kernel<false,false,0,false>"
     out = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
@@ -282,7 +282,7 @@ def test_config3_water_4k_properties(gpu_ctx, water_scene):
     gpu_ctx.render_device(f, bufs[1].data_ptr(), d_tree_hash=hsh.data_ptr())
     gpu_ctx.sync()
     assert torch.equal(bufs[0], bufs[1])
-    assert gpu_ctx.kernel_name() == "render_kernel<false,false,2,true>"  # dark-material scene: refinement at any size
+    assert gpu_ctx.kernel_name() == "render_kernel<false,false,2,true>"  # no side kernel behind rt_render_device: cull refinement
     full = bufs[0].cpu().numpy().view(np.uint32)
     assert full[1, 0] == 0 and full[0, 0] == water_scene.sky_0rgb
     for y0, y1 in ((0, 97), (1000, 1100), (2100, 2160)):
