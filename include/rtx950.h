@@ -223,11 +223,14 @@ typedef enum rt_tuning {
     RT_TUNE_WAVEFRONT_CAP = 10, /* items (ray bundles) per deeper level that the wavefront buffers hold; 0 (default) = from
                                    the frame size.  Tiles whose bundles do not fit are rendered by the tile-resident
                                    kernel instead, so tests lower it to force that path.  Next render call            */
-    RT_TUNE_CULL_REFINE = 11,   /* -1 (default, automatic), 0 or 1: the plain short-list kernel without / with the cull
-                                   refinement (the box form of the wave-level cull applied where the one-radius form
-                                   leaves 20 candidates or more).  Automatic: on, unless the side kernel for heavy
-                                   tiles is in use (it takes the slowest tiles anyway).  Results do not depend on
-                                   it.  Next render call                                                      */
+    RT_TUNE_CULL_REFINE = 11,   /* -1 (default, automatic), 0, 1 or 2: the plain short-list kernel without / with the
+                                   cull refinement (1: the box form of the wave-level cull applied where the one-radius
+                                   form leaves 20 candidates or more) / with the refinement and the walk by bundles (2:
+                                   a wave whose secondary rays left through different faces is walked bundle by bundle
+                                   where its cull is loose).  Automatic: 2 for launches of at most 65536 tiles (bound by
+                                   their slowest tiles), 1 for larger ones, 0 when the side kernel for heavy tiles is in
+                                   use (it takes the slowest tiles anyway).  Results do not depend on it.  Next render
+                                   call                                                                        */
     RT_TUNE_BVH_DEPTH_LIMIT = 5 /* deepest BVH the per-lane walk takes (1..28, default 28 = the walk's stack);
                                    a deeper tree sends every wave through the chunk traversal.  28 levels
                                    cannot be exceeded by a real list, so tests lower it.  Next rt_scene_upload */

@@ -146,8 +146,8 @@ struct rt_ctx {
     TileScratch own;  // tile stamps, work queue, tile costs of this context's launches
     WfScratch wf;     // item, node and ray buffers of the wavefront path
     int tune_wavefront = -1;      // -1: automatic, 0: never, 1: every plain frame
-    int tune_cull_refine = -1;    // -1: automatic (render_part), 0 / 1: plain short-list kernel without / with the cull refinement
-    bool last_refine = false;     // what the last plain launch used (rt_kernel_name)
+    int tune_cull_refine = -1;    // -1: automatic (refine_choice), 0 / 1 / 2: plain short-list kernel without / with the cull refinement / with refinement and bundles
+    uint32_t last_refine = 0;     // what the last plain launch used (rt_kernel_name)
     uint32_t tune_wf_cap = 0;     // items per deeper level (0: from the tile grid)
     bool scene_has_children = false;  // some material reflects or refracts: the ray tree can be deeper than its root
     // rt_render_multi: this context's compact part of the frame, and the event that says it has reached GPU0
@@ -619,6 +619,28 @@ int launch_wavefront(rt_ctx* ctx, const Params& p)
         ctx->events.push_back(ev);
     }
     return RT_OK;
+}
+
+// Params::refine of a plain launch of `launch_tiles` tiles: which short-list kernel renders it.
+//  1  the cull refinement (render_kernel<.., 2, ..>): where the one-radius cull leaves many candidates the box form of
+//     the cull is applied as well.  It shortens the slowest tiles (1080p one frame at a time -15 %, 4K with the water
+//     platform -14 %, 4K diorama -4 %, 8K -4 %); its code used to cost the common path 4 % in register allocation and was
+//     kept to launches bound by their slowest tiles, until the kernels got 35 registers back (pow_f64_rounded).
+//  2  the refinement and the walk by bundles (render_kernel<.., 3, ..>; cube_query's SPLIT == 2): a wave whose secondary
+//     rays left in several bundles (a tile across the edge between two faces) and whose cull is loose is walked bundle
+//     by bundle.  The slowest tiles' candidates drop several times (1080p 0.0570 -> 0.0479 ms with two frames in flight,
+//     0.1106 -> 0.0874 one at a time; 4K with water one at a time 0.272 -> 0.215), and the keys' bookkeeping costs every
+//     other tile 7 % (4K diorama 0.1333 -> 0.1429, 8K +9 %): for launches bound by their slowest tiles, i.e. at most
+//     65 536 tiles (1080p; the parts of an N-GPU split of a 4K frame).
+//  0  neither: with the side kernel, which takes the slowest tiles anyway (the refinement changes the tiles' one-wave
+//     costs against their three-wave costs, tiles then change sides from frame to frame, and the pair is slower than
+//     the side kernel alone: 1080p one frame at a time 0.072 ms without the refinement, 0.099 with it); long lists.
+uint32_t refine_choice(const rt_ctx* ctx, bool heavy_on, size_t launch_tiles)
+{
+    if (ctx->base.n_chunks != 0u) return 0u;
+    if (ctx->tune_cull_refine >= 0) return (uint32_t)ctx->tune_cull_refine;
+    if (heavy_on) return 0u;
+    return launch_tiles <= kAutoHeavyMaxTiles ? 2u : 1u;
 }
 
 // The host has just waited for the context's stream.  If a launch since the last check used the side kernel, read
@@ -1199,16 +1221,8 @@ static int render_part(rt_ctx* ctx, const rt_frame* frame, uint32_t n_parts, uin
             p.prefilled = 1u;
         }
     }
-    // The cull refinement (render_kernel<.., 2, ..>, short lists): where the one-radius cull leaves many candidates the
-    // box form of the cull is applied as well.  It shortens the slowest tiles (1080p one frame at a time -15 %, 4K with
-    // the water platform -14 %, 4K diorama -4 %, 8K -4 %); its code used to cost the common path 4 % in register
-    // allocation and was kept to launches bound by their slowest tiles, until the kernels got 35 registers back
-    // (pow_f64_rounded): now on for every short-list launch.
-    // Not together with the side kernel, which takes the slowest tiles anyway: the refinement changes the tiles' one-wave
-    // costs against their three-wave costs, tiles then change sides from frame to frame, and the pair is slower than the
-    // side kernel alone (1080p one frame at a time: 0.072 ms without the refinement, 0.099 with it).
-    p.refine = (ctx->base.n_chunks == 0u && (ctx->tune_cull_refine >= 0 ? ctx->tune_cull_refine == 1 : !heavy_on)) ? 1u : 0u;
-    if (variant == kVariantRender) ctx->last_refine = p.refine != 0u;
+    p.refine = refine_choice(ctx, heavy_on, launch_tiles);
+    if (variant == kVariantRender) ctx->last_refine = p.refine;
     if (wavefront) return launch_wavefront(ctx, p);
     if ((rc = launch_timed(ctx, p, variant)) != RT_OK) return rc;
     if (heavy_now) {
@@ -1532,7 +1546,7 @@ int rt_set_tuning(rt_ctx* ctx, int key, double value)
         ctx->tune_wavefront = (int)value;
         return RT_OK;
     case RT_TUNE_CULL_REFINE:
-        if (!tri) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_CULL_REFINE must be -1 (automatic), 0 or 1");
+        if (!(tri || value == 2.0)) return fail(ctx, RT_ERR_INVALID_ARG, "RT_TUNE_CULL_REFINE must be -1 (automatic), 0, 1 or 2");
         ctx->tune_cull_refine = (int)value;
         return RT_OK;
     case RT_TUNE_WAVEFRONT_CAP:
@@ -1595,8 +1609,8 @@ int rt_render_device_noalloc(rt_ctx* ctx, const rt_frame* frame, uint32_t* d_out
         p.prefilled = 1u;
     }
     // the same choice of kernel variant as rt_render_device (no side kernel here)
-    p.refine = (ctx->base.n_chunks == 0u && (ctx->tune_cull_refine >= 0 ? ctx->tune_cull_refine == 1 : true)) ? 1u : 0u;
-    ctx->last_refine = p.refine != 0u;
+    p.refine = refine_choice(ctx, false, (size_t)frame_tiles);
+    ctx->last_refine = p.refine;
     if ((rc = listing(ctx, p, kVariantRender)) != RT_OK) return rc;
     hipError_t e = (hipError_t)launch_render(p, kVariantRender, (void*)ctx->stream, ctx->max_workgroups);
     if (e != hipSuccess) return fail_hip(ctx, e, "render kernel launch");
@@ -1788,6 +1802,7 @@ const char* rt_kernel_name(const rt_ctx* ctx)
     if (!ctx || !ctx->has_scene) return "";
     const bool large = ctx->base.n_chunks > 0u, dark = ctx->base.dark_materials != 0u;  // launch_render's choice
     if (large) return dark ? "render_kernel<false,false,1,true>" : "render_kernel<false,false,1,false>";
+    if (ctx->last_refine == 2u) return dark ? "render_kernel<false,false,3,true>" : "render_kernel<false,false,3,false>";
     if (ctx->last_refine) return dark ? "render_kernel<false,false,2,true>" : "render_kernel<false,false,2,false>";
     return dark ? "render_kernel<false,false,0,true>" : "render_kernel<false,false,0,false>";
 }

@@ -166,8 +166,8 @@ struct Params {
     // flight: 1.23 -> 0.94 ms)
     uint32_t bvh_levels;
     float split_thr;  // heavy tiles: a wave whose cull inflation exceeds this is walked bundle by bundle (cube_query, SPLIT)
-    // 1: the plain short-list kernel with the cull refinement (render_kernel<.., 2, ..>): launches that are bound by their
-    // slowest tiles - small frames, the parts of an N-GPU split, scenes with deep ray trees.  Host-side only.
+    // which plain short-list kernel: 0 render_kernel<.., 0, ..>, 1 with the cull refinement (<.., 2, ..>), 2 with the
+    // refinement and the walk by bundles (<.., 3, ..>); the host's choice per launch (refine_choice).  Host-side only.
     uint32_t refine;
     uint32_t heavy_spin_limit;  // heavy_join: polls before it gives up (0: 2^24; 1: report at once, RT_TUNE_HEAVY_SPIN_LIMIT)
     // ---- wave-uniform float values that the kernels would otherwise compute once per wave and then hold in vector

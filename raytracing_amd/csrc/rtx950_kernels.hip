@@ -1145,8 +1145,9 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
 }
 
 // LARGE (a kernel template parameter chosen by the length of the cube list: 0 short, 1 long) keeps the long-list
-// code out of the kernel that renders short lists: compiled in, it cost the 97-cube benchmark scene 6 %.  LARGE == 2:
-// a short list with the cull refinement of cube_query_small (kRefineMin), chosen per launch (Params::refine).
+// code out of the kernel that renders short lists: compiled in, it cost the 97-cube benchmark scene 6 %.  LARGE >= 2:
+// a short list with the cull refinement of cube_query_small (kRefineMin); LARGE == 3: and with bundle keys (render_kernel,
+// cube_query's SPLIT == 2); chosen per launch (Params::refine).
 template <int MODE, int LARGE, uint32_t WAVES, typename CP>
 DEV void cube_query_run(const Params& P, const RayPre& q, const CP& cp, bool active, V3 o, V3 d, uint32_t impact_id, QState& st PROF_ARG)
 {
@@ -1156,11 +1157,12 @@ DEV void cube_query_run(const Params& P, const RayPre& q, const CP& cp, bool act
         if (coherent) cube_query_large<MODE, CP>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
         else cube_query_bvh<MODE, WAVES>(P, q, active, o, d, impact_id, st PROF_PASS);
     } else {
-        cube_query_small<MODE, CP, LARGE == 2>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+        cube_query_small<MODE, CP, LARGE >= 2>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
     }
 }
 
-// SPLIT (heavy tiles only, render_heavy_kernel's tracer and shaders): a wave whose rays come in several
+// SPLIT (1: heavy tiles, render_heavy_kernel's tracer and shaders, with the general cull; 2: render_kernel<.., 3, ..>,
+// with the one-radius cull): a wave whose rays come in several
 // bundles - an 8x8 tile across the edge between two faces sends its secondary rays two ways, and the
 // reference's negative-distance rule can put the hit points of one bundle on the far side of the scene -
 // has a wave-level bound that keeps every cube.  `key` names a lane's bundle (the faces its ray tree has
@@ -1168,14 +1170,33 @@ DEV void cube_query_run(const Params& P, const RayPre& q, const CP& cp, bool act
 // key by key, each bundle with its own bound (at most kMaxBundles passes, the last takes all the rest).
 // The folds are per lane, so the order and grouping of the passes change no result.
 constexpr uint32_t kMaxBundles = 3u;
-template <int MODE, int LARGE, bool SPLIT = false>
+template <int MODE, int LARGE, int SPLIT = 0>
 DEV void cube_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_id, QState& st, uint32_t key PROF_ARG)
 {
     if (P.n_cubes == 0u) return;
     const RayPre q = ray_pre(P, o, d);
     st.tol = q.tol;
     st.div_ok = q.div_ok;
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT == 2) {
+        // render_kernel: the one-radius cull, and bundle by bundle where it is loose and the wave holds several bundles
+        const CullPre cp = cull_pre(active, o, d, q.wild, P.cull_slack);
+        const unsigned long long am = wave_ballot(active);
+        const uint32_t key0 = (uint32_t)__builtin_amdgcn_readlane((int)key, am ? (int)__builtin_ctzll(am) : 0);
+        if (!cp.all && (__builtin_fmaf(2.0f * P.bound_max, cp.dr, cp.wr_raw) > P.split_thr) && wave_any(active && key != key0)) {
+            bool rem = active;
+            for (uint32_t b = 0; b < kMaxBundles; ++b) {
+                const unsigned long long rm = wave_ballot(rem);
+                if (rm == 0ull) break;
+                const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(rm));
+                const bool sel = rem && ((b + 1u == kMaxBundles) || (key == kb));
+                const CullPre cpb = cull_pre(sel, o, d, q.wild, P.cull_slack);
+                cube_query_run<MODE, LARGE, 1u, CullPre>(P, q, cpb, sel, o, d, impact_id, st PROF_PASS);
+                rem = rem && !sel;
+            }
+            return;
+        }
+        cube_query_run<MODE, LARGE, 1u, CullPre>(P, q, cp, active, o, d, impact_id, st PROF_PASS);
+    } else if constexpr (SPLIT == 1) {
         // heavy tiles: the general cull (cull_pre_g), and bundle by bundle where that is still loose
         const CullPreG cp = cull_pre_g(active, o, d, q.wild, P.cull_slack);
         const unsigned long long am = wave_ballot(active);
@@ -1258,7 +1279,7 @@ DEV void sphere_query(const Params& P, bool active, V3 o, V3 d, uint32_t impact_
 
 // ---------------------------------------------------------------- nearest hit (render.rs:87-101)
 // `pass` is wave-uniform: PASS_SPHERES walks the sphere list, PASS_CUBES the cube list.
-template <bool COUNT, int LARGE, bool SPLIT = false>
+template <bool COUNT, int LARGE, int SPLIT = 0>
 DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3 d, bool& div_ok, Counters& cnt, uint32_t key PROF_ARG)
 {
     uint32_t best_idx = kNoHit;
@@ -1303,7 +1324,7 @@ DEV uint32_t nearest_query(const Params& P, uint32_t pass, bool active, V3 o, V3
 // ---------------------------------------------------------------- shadow (render.rs:44-70)
 // First object in array order, among those whose id differs from the impact object's
 // (render.rs:113), whose ray_intersect returns Some.  Not the nearest one.
-template <bool COUNT, int LARGE, bool SPLIT = false>
+template <bool COUNT, int LARGE, int SPLIT = 0>
 DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V3 light_pos, V3 dir, uint32_t impact_id, uint32_t& blocker, Counters& cnt, uint32_t key PROF_ARG)
 {
     // dir = normalize(light_pos - origin) (render.rs:46), the caller's light_dir: the same expression
@@ -1387,7 +1408,7 @@ enum { F_RO = 0, F_RD = 3, F_SUMF = 6, F_C0 = 7, F_KR = 8, F_KT = 9, F_H = 10, F
 constexpr uint32_t kEntryNoCubes = 1u << 15;  // queue entry flag: the tile's cube pass is answered without tracing
 constexpr uint32_t kPaintGroup = 16;  // untraced tiles painted per surplus workgroup
 constexpr int kStackDepth = 3;  // nodes at depth 0..2 can wait for traced children (max_depth <= 3)
-template <bool DBG, bool SPLIT = false>
+template <bool DBG, int SPLIT = 0>
 constexpr int frame_words() { return DBG ? 12 : (SPLIT ? 11 : 10); }
 constexpr int F_KEY = 10;  // SPLIT (plain variants only): the bundle key of the node's refraction child
 constexpr uint32_t kHitFlag = 1u << 24;  // in F_SUMF, above the packed 0x00RRGGBB light sum
@@ -1495,7 +1516,7 @@ DEV uint32_t mail_collect(const Mailbox& mb, uint32_t depth)
 // One iteration of the light fold of cast_ray (render.rs:104-152, :221-224 without the children): the term
 // (diffuse + specular) * (1 - reflectivity - transparency) of light `li` for the wave's hit points.  `lit`:
 // lanes that cast the shadow ray (a hit whose direct light is not exactly black, see trace_tree).
-template <bool DBG, bool COUNT, int LARGE, bool SPLIT = false>
+template <bool DBG, bool COUNT, int LARGE, int SPLIT = 0>
 DEV Col light_term(const Params& P, uint32_t pass, uint32_t li, bool lit, bool hit_any, V3 hit_p, V3 hit_n, uint32_t hit_id, V3 view_dir, Col tx_a,
                    float m_specular, float m_albedo1, float k_ds, float ambient, uint32_t& h, Counters& cnt, uint32_t key PROF_ARG)
 {
@@ -1542,7 +1563,7 @@ DEV Col light_term(const Params& P, uint32_t pass, uint32_t li, bool lit, bool h
 // 64 primary rays: returns the packed colour, the primary hit index and the tree hash per lane.
 // ASYNC (render_heavy_kernel's tracer, plain variant only): the light fold of a node is posted to the
 // workgroup's shader waves (`mb`) and its sum collected when the node is finished.
-template <bool DBG, bool COUNT, int LARGE, bool DARK, bool ASYNC = false, bool SPLIT = ASYNC>
+template <bool DBG, bool COUNT, int LARGE, bool DARK, bool ASYNC = false, int SPLIT = (ASYNC ? 1 : 0)>
 DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d, float ambient, uint32_t* stk, uint32_t& hash, uint32_t& hit_idx,
                         Totals& tot, const Mailbox& mb PROF_ARG)
 {
@@ -1867,7 +1888,8 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
 template <bool DBG, bool COUNT, int LARGE, bool DARK = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU, LARGE == 1 ? RTX_WAVES_PER_EU_LARGE : RTX_WAVES_PER_EU))) void render_kernel(const Params P)
 {
-    __shared__ uint32_t stk[kStackDepth * frame_words<DBG>() * 64];
+    constexpr int KEYS = (!DBG && !COUNT && LARGE == 3) ? 2 : 0;  // bundle keys: cube_query's SPLIT == 2
+    __shared__ uint32_t stk[kStackDepth * frame_words<DBG, KEYS>() * 64];
     const uint32_t lane = threadIdx.x & 63u;
     Totals cnt;
 #pragma unroll
@@ -1974,7 +1996,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ?
                 }
             } else {
                 const Mailbox none{nullptr, nullptr, nullptr};
-                c = trace_tree<DBG, COUNT, LARGE, DARK>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt, none PROF_PASS);
+                c = trace_tree<DBG, COUNT, LARGE, DARK, false, KEYS>(P, pass, active, eye, dir, pass == PASS_SPHERES ? 1.0f : P.ambient, stk, hh, hi, cnt, none PROF_PASS);
             }
             if (pass == PASS_SPHERES) { px = c; hs = hh; hit_s = hi; }
             else { px = (px == P.sky) ? c : px; hc = hh; hit_c = hi; }
@@ -2757,10 +2779,12 @@ int launch_render(const Params& p, int variant, void* stream, uint32_t max_workg
     default:
         if (p.dark_materials != 0u) {
             if (large) hipLaunchKernelGGL((render_kernel<false, false, 1, true>), grid, block, lds, s, p);
+            else if (p.refine == 2u) hipLaunchKernelGGL((render_kernel<false, false, 3, true>), grid, block, lds, s, p);
             else if (p.refine != 0u) hipLaunchKernelGGL((render_kernel<false, false, 2, true>), grid, block, lds, s, p);
             else hipLaunchKernelGGL((render_kernel<false, false, 0, true>), grid, block, lds, s, p);
         } else {
             if (large) hipLaunchKernelGGL((render_kernel<false, false, 1>), grid, block, lds, s, p);
+            else if (p.refine == 2u) hipLaunchKernelGGL((render_kernel<false, false, 3>), grid, block, lds, s, p);
             else if (p.refine != 0u) hipLaunchKernelGGL((render_kernel<false, false, 2>), grid, block, lds, s, p);
             else hipLaunchKernelGGL((render_kernel<false, false, 0>), grid, block, lds, s, p);
         }

@@ -245,14 +245,14 @@ def test_full_size_properties(gpu_ctx, default_scene):
 
 def test_config2_1080p_against_the_oracle(gpu_ctx, oracle_mod, default_scene):
     """BASELINE.json config 2 at its exact size: the diorama at 1920x1080, depth 3 - debug and plain kernels (the
-    plain one is the cull-refinement variant at this size) against the oracle run here on every pixel: hit planes,
+    plain one is the variant with cull refinement and bundles at this size) against the oracle run here on every pixel: hit planes,
     ray-tree hashes and colours bit-exact, counters equal (about half a second of host threads)."""
     import torch
     f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, default_scene, 1920, 1080)
     rep = assert_parity(gfb, gpl, ofb, opl, "config 2: 1920x1080")
     assert rep["exact_fraction"] == 1.0, rep
     # _both's plain frame came from the synchronous rt_render (side kernel for the slowest tiles, hence no cull
-    # refinement); the asynchronous entry point takes the cull-refinement variant: the same frame, twice in a row
+    # refinement); the asynchronous entry point takes the variant with refinement and bundles: the same frame, twice in a row
     assert gpu_ctx.kernel_name() == "render_kernel<false,false,0,false>"
     out = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
@@ -260,7 +260,7 @@ def test_config2_1080p_against_the_oracle(gpu_ctx, oracle_mod, default_scene):
         gpu_ctx.render_device(f, out.data_ptr())
         gpu_ctx.sync()
         assert np.array_equal(out.cpu().numpy().view(np.uint32), gfb)
-    assert gpu_ctx.kernel_name() == "render_kernel<false,false,2,false>"
+    assert gpu_ctx.kernel_name() == "render_kernel<false,false,3,false>"  # at most 65536 tiles: refinement and bundles
     c = gpu_ctx.count_rays(f)
     assert c.uniq_dict() == ocnt.uniq_dict()
     assert gfb[1, 0] == 0
@@ -759,12 +759,13 @@ def test_side_kernel_moving_camera_empty_and_full_lists():
             c.close()
 
 
-@pytest.mark.parametrize("refine", [0, 1])
+@pytest.mark.parametrize("refine", [0, 1, 2])
 def test_cull_refinement_forced(tuned_ctx, oracle_mod, default_scene, water_scene, refine):
     """RT_TUNE_CULL_REFINE: the plain short-list kernel without / with the cull refinement (the box form of the
-    wave-level cull applied to chunks where the one-radius form leaves 20 candidates or more; automatic mode turns
-    it on for small launches and dark-material scenes).  Either kernel paints the debug variant's frame (which has
-    no refinement) and the oracle's: the diorama from four sides, the water variant, a dense random scene, 16 lights."""
+    wave-level cull applied to chunks where the one-radius form leaves 20 candidates or more) / with the refinement
+    and the walk by bundles (waves whose secondary rays left through different faces).  Each kernel paints the debug
+    variant's frame (which has neither) and the oracle's: the diorama from four sides, the water variant, a dense
+    random scene, 16 lights."""
     ctx = tuned_ctx
     ctx.set_tuning(rt.RT_TUNE_CULL_REFINE, refine)
     s = default_scene
@@ -778,7 +779,7 @@ def test_cull_refinement_forced(tuned_ctx, oracle_mod, default_scene, water_scen
     for sc, w, h, kw in cases:
         f, gfb, gpl, ofb, opl, ocnt = _both(ctx, oracle_mod, sc, w, h, **kw)
         assert_parity(gfb, gpl, ofb, opl, f"cull refinement {refine}: {sc.name} {w}x{h}")
-    assert ctx.kernel_name() == f"render_kernel<false,false,{2 if refine else 0},false>"
+    assert ctx.kernel_name() == f"render_kernel<false,false,{(0, 2, 3)[refine]},false>"
     for seed in range(300, 312):
         sc, label = random_scene(rt, default_scene, seed, 250)
         f, gfb, gpl, ofb, opl, ocnt = _both(ctx, oracle_mod, sc, 96, 64)
