@@ -8,7 +8,7 @@ s = rt.default_scene(with_water=water)
 ctx = rt.Context(0); ctx.upload(s)
 out = torch.zeros((H, W), dtype=torch.int32, device="cuda"); torch.cuda.synchronize()
 f = s.frame(W, H)
-for refine in (1,):
+for refine in (1, 2):
     ctx.set_tuning(rt.RT_TUNE_CULL_REFINE, refine)
     for _ in range(20):
         ctx.render_device(f, out.data_ptr())
