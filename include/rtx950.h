@@ -255,7 +255,8 @@ const char* rt_last_error(const rt_ctx* ctx);
 /* Upload the static part of `Model`: cubes, spheres (src/lib.rs:43-44), the material table
  * (src/material.rs:34-122) and the texture atlases (src/texture.rs:22-32, loaded by
  * `Texture::new`, :141-169, as row-major RGB8: 3 bytes per texel, `idx = y*width + x`).
- * Host arrays are copied; the caller keeps ownership.  n_cubes / n_spheres may be 0.
+ * Host arrays are copied; the caller keeps ownership.  n_cubes / n_spheres may be 0; more than 2^26 cubes or
+ * 2^31 - 1 spheres are refused (RT_ERR_UNSUPPORTED).
  *   atlas_rgb8 — n_textures consecutive images of tex_w*tex_h*3 bytes
  *   sprite     — `sprite_size` (16 in the reference, src/texture.rs:59-67)
  */

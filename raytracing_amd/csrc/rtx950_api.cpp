@@ -779,7 +779,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "ctx is null");
     if ((n_cubes && !cubes) || (n_spheres && !spheres)) return fail(ctx, RT_ERR_INVALID_ARG, "object array is null");
     if (!materials || n_materials == 0) return fail(ctx, RT_ERR_INVALID_ARG, "material table is empty");
-    if (n_cubes > 0x0FFFFFFFu || n_spheres > 0x7FFFFFFFu) return fail(ctx, RT_ERR_UNSUPPORTED, "too many objects");
+    // 2^26 cubes: the BVH walk addresses a pair of sibling boxes (64 bytes) by a 32-bit byte offset (cube_query_bvh)
+    if (n_cubes > 0x04000000u || n_spheres > 0x7FFFFFFFu) return fail(ctx, RT_ERR_UNSUPPORTED, "too many objects (at most 2^26 cubes, 2^31 - 1 spheres)");
     if (n_textures && (!atlas_rgb8 || tex_w == 0 || tex_h == 0 || sprite == 0)) return fail(ctx, RT_ERR_INVALID_ARG, "bad atlas description");
     if (n_textures && ((uint64_t)n_textures * tex_w * tex_h > 0x3FFFFFFFull)) return fail(ctx, RT_ERR_UNSUPPORTED, "atlas too large");
     for (size_t i = 0; i < n_materials; ++i) {

@@ -63,7 +63,7 @@ struct LightRec {
 };
 
 constexpr int kMaxLights = 16;
-constexpr uint32_t kBvhStackMax = 28;  // deferred siblings per lane: one per level; 2^28 cubes at most
+constexpr uint32_t kBvhStackMax = 28;  // deferred siblings per lane: one per level (rt_scene_upload takes at most 2^26 cubes)
 constexpr uint32_t kRowBlock = 16;  // rows per workgroup tile and per interleave block
 
 struct Params {

@@ -1095,8 +1095,11 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
         PROF_COUNT(MODE == Q_SHADOW ? 4 : 3, 1);  // profile builds: walk steps (drown the few amb counts of these slots)
         const bool on = pair != kNone;
         st.ev_bvh += on ? 1u : 0u;
-        const size_t pi = on ? (size_t)pair * 4u : 0u;
-        const f32x4 ac = nodes[pi], ah = nodes[pi + 1u], bc = nodes[pi + 2u], bh = nodes[pi + 3u];
+        // a 32-bit byte offset from the uniform base (pairs are 64 bytes, rt_scene_upload takes at most 2^26 cubes): one
+        // address register and no 64-bit arithmetic per step (10k-cube world -1.2 %)
+        const uint32_t off = on ? pair * 64u : 0u;
+        const f32x4* pn = (const f32x4*)((const char*)nodes + off);
+        const f32x4 ac = pn[0], ah = pn[1], bc = pn[2], bh = pn[3];
         const float ac3 = ac[3], ah3 = ah[3], bc3 = bc[3], bh3 = bh[3];  // scalar copies first: see the note at u2f
         const uint32_t fca = __builtin_bit_cast(uint32_t, ac3), fcb = __builtin_bit_cast(uint32_t, bc3);
         const uint32_t link_a = __builtin_bit_cast(uint32_t, ah3), link_b = __builtin_bit_cast(uint32_t, bh3);
