@@ -6,7 +6,9 @@ RTX950_SOAK_HEAVY=k (read here, by the tool): also renders every scene three mor
 rt_set_tuning(RT_TUNE_HEAVY_CLASS, k), so that the side kernel (three-wave workgroups, general cull, bundles)
 traces the tiles of cost class >= k; those frames must equal the debug variant's too.
 RTX950_SOAK_WAVEFRONT=1: the plain frames are rendered by the wavefront launches (RT_TUNE_WAVEFRONT), twice each,
-every third scene with the item capacity cut to 128 (RT_TUNE_WAVEFRONT_CAP: overflowing tiles take the redo list)."""
+every third scene with the item capacity cut to 128 (RT_TUNE_WAVEFRONT_CAP: overflowing tiles take the redo list).
+RTX950_SOAK_REFINE=1: also renders every scene with the side kernel off and each plain short-list kernel forced in turn
+(RT_TUNE_CULL_REFINE 0, 1, 2: plain, cull refinement, refinement and the walk by bundles)."""
 import os
 import sys
 
@@ -24,6 +26,7 @@ base = rt.default_scene()
 ctx = rt.Context(0)
 soak_heavy = os.environ.get("RTX950_SOAK_HEAVY")
 soak_wf = os.environ.get("RTX950_SOAK_WAVEFRONT") == "1"
+soak_refine = os.environ.get("RTX950_SOAK_REFINE") == "1"
 bad = 0
 worst = 1.0
 for seed in range(first, first + count):
@@ -50,6 +53,13 @@ for seed in range(first, first + count):
                 assert (ctx.render(f) == gfb).all(), f"{label}: side kernel (class >= {soak_heavy}), launch {k}: frame differs"
             ctx.set_tuning(rt.RT_TUNE_HEAVY_CLASS, -1)
             assert ctx.debug_status() == 0, f"{label}: a wait between the streams gave up"
+        if soak_refine:
+            ctx.set_tuning(rt.RT_TUNE_HEAVY_CLASS, 8)
+            for r in (0, 1, 2):
+                ctx.set_tuning(rt.RT_TUNE_CULL_REFINE, r)
+                assert (ctx.render(f) == gfb).all(), f"{label}: plain kernel with RT_TUNE_CULL_REFINE {r}: frame differs"
+            ctx.set_tuning(rt.RT_TUNE_CULL_REFINE, -1)
+            ctx.set_tuning(rt.RT_TUNE_HEAVY_CLASS, -1)
         worst = min(worst, rep["exact_fraction"])
         assert ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict(), f"{label}: ray counters differ"
     except AssertionError as e:
