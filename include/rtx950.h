@@ -392,7 +392,8 @@ int rt_selftest_division(rt_ctx* ctx, uint32_t seed, uint64_t n_cases, uint64_t*
 
 /* Name of the render kernel instantiation that rt_render / rt_render_device launch for the uploaded scene,
  *  e.g. "render_kernel<false,false,0,false>" (template arguments: debug planes, counters, cube list kind - 0 short,
- * 1 long, 2 short with the cull refinement, as chosen by the context's last plain launch -, dark-material test), as it
+ * 1 long, 2 short with the cull refinement, 3 short with the refinement and the walk by bundles, as chosen by the
+ * context's last plain launch (RT_TUNE_CULL_REFINE) -, dark-material test), as it
  * appears in a rocprofv3 kernel trace (there with spaces after the commas); with RT_TUNE_HEAVY_CLASS in effect
  * render_heavy_kernel<long list, dark-material test> runs beside it.  No reference counterpart. */
 const char* rt_kernel_name(const rt_ctx* ctx);
