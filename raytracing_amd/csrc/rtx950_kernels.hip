@@ -630,34 +630,15 @@ struct CullPre {  // wave-uniform
     bool all;                   // some active ray is non-finite or huge: keep every cube
 };
 
-// max over the 64 lanes of two non-negative floats at once.  Each is rounded UP to its top 16 bits (a
-// bfloat16; ordered like an unsigned integer), the pair shares a dword, and v_pk_max_u16 does both lane
-// reductions in one DPP sweep; the results (<= 2^-7 above the true maxima, which only loosens the cull by
-// that much) come back as floats.  +inf rounds up to a NaN pattern: compares with it are false, which
-// keeps every cube, as it should.
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-template <int CTRL, int ROW_MASK>
-DEV uint32_t dpp_u(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-DEV uint32_t pk_max_u16(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
+// max over the 64 lanes of two non-negative floats.  (Rounds 1-2 packed the pair as two bfloat16 halves of a dword and
+// reduced both with v_pk_max_u16: twelve instructions for the sweep plus six to pack, results up to 2^-7 above the
+// true maxima.  VOP3P takes no DPP modifier, v_max_u32 does: two exact sweeps are shorter.)
 DEV void wave_max2(float a, float b, float& out_a, float& out_b)
 {
-    const uint32_t ua = (__builtin_bit_cast(uint32_t, a) >> 16) + 1u, ub = (__builtin_bit_cast(uint32_t, b) >> 16) + 1u;
-    uint32_t v = (ua << 16) | (ub & 0xFFFFu);
-    v = pk_max_u16(v, dpp_u<0x111, 0xf>(v));
-    v = pk_max_u16(v, dpp_u<0x112, 0xf>(v));
-    v = pk_max_u16(v, dpp_u<0x114, 0xf>(v));
-    v = pk_max_u16(v, dpp_u<0x118, 0xf>(v));
-    v = pk_max_u16(v, dpp_u<0x142, 0xa>(v));
-    v = pk_max_u16(v, dpp_u<0x143, 0xc>(v));
-    const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-    out_a = __builtin_bit_cast(float, r & 0xFFFF0000u);
-    out_b = __builtin_bit_cast(float, r << 16);
+    // non-negative floats order like their bit patterns: two v_max_u32 sweeps (the DPP modifier folds into the
+    // instruction), exact maxima.  A NaN's pattern is above every number's: it wins, and compares with it are false.
+    out_a = __builtin_bit_cast(float, wave_max_u32(__builtin_bit_cast(uint32_t, a)));
+    out_b = __builtin_bit_cast(float, wave_max_u32(__builtin_bit_cast(uint32_t, b)));
 }
 
 // origin_bound: an upper bound of every active lane's origin coordinates (Params::origin_bound; lanes
