@@ -5,6 +5,7 @@
 # run of its own as the harness asks.  Usage (on the GPU box): bash tools/profile_workloads.sh <tag> [workloads...]
 #   -> gpurun_out/prof_<tag>/<workload>/{trace,pmc_*}; summarise with tools/summarize_workloads.py
 set -o pipefail
+# (a gpurun merge adds files to what an earlier run of the same tag left in gpurun_out/: delete the local directory first)
 TAG=${1:-r2}; shift || true
 WORKLOADS=${*:-"minecraft_4k minecraft_1080p minecraft_water_4k synthetic_4k minecraft_8k_orbit"}
 export TMPDIR=/tmp
