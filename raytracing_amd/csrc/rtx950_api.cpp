@@ -632,9 +632,10 @@ int launch_wavefront(rt_ctx* ctx, const Params& p)
 //     0.1106 -> 0.0874 one at a time; 4K with water one at a time 0.272 -> 0.215), and the keys' bookkeeping costs every
 //     other tile 7 % (4K diorama 0.1333 -> 0.1429, 8K +9 %): for launches bound by their slowest tiles, i.e. at most
 //     65 536 tiles (1080p; the parts of an N-GPU split of a 4K frame).
-//  0  neither: with the side kernel, which takes the slowest tiles anyway (the refinement changes the tiles' one-wave
-//     costs against their three-wave costs, tiles then change sides from frame to frame, and the pair is slower than
-//     the side kernel alone: 1080p one frame at a time 0.072 ms without the refinement, 0.099 with it); long lists.
+//  0  neither: with the side kernel, which takes the slowest tiles anyway (1080p one frame at a time: 0.0707 ms with
+//     the plain kernel beside it, 0.0716 with the refinement, 0.0728 with bundles; before the register changes the
+//     refinement cost more there, 0.099: it changes the tiles' one-wave costs against their three-wave costs, and
+//     tiles then change sides from frame to frame); long lists.
 uint32_t refine_choice(const rt_ctx* ctx, bool heavy_on, size_t launch_tiles)
 {
     if (ctx->base.n_chunks != 0u) return 0u;
