@@ -325,6 +325,12 @@ def test_error_paths(gpu_ctx, default_scene):
         with pytest.raises(rt.RtError) as e:
             fresh.render(default_scene.frame(8, 8))
         assert e.value.code == rt._ffi.RT_ERR_NO_SCENE
+        # more cubes than the BVH walk's 32-bit pair offsets reach are refused before any array is read
+        import ctypes as C
+        s = default_scene
+        rc = fresh._lib.rt_scene_upload(fresh._ctx, C.cast(s.cubes, C.POINTER(rt.Cube)), (1 << 26) + 1, None, 0,
+                                        C.cast(s.materials, C.POINTER(rt.Material)), len(s.materials), None, 0, 0, 0, 16)
+        assert rc == rt._ffi.RT_ERR_UNSUPPORTED and b"2^26" in fresh._lib.rt_last_error(fresh._ctx)
 
 
 def test_empty_scene_and_ragged_sizes(gpu_ctx, oracle_mod, default_scene):
