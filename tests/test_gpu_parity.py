@@ -266,6 +266,26 @@ def test_config2_1080p_against_the_oracle(gpu_ctx, oracle_mod, default_scene):
     assert gfb[1, 0] == 0
 
 
+@pytest.mark.parametrize("water", [False, True])
+def test_config3_4k_against_the_oracle(gpu_ctx, oracle_mod, default_scene, water_scene, water):
+    """BASELINE.json configs 2/3 at 3840x2160, with and without the water platform, against the oracle run here on all
+    8.3 M pixels (a few seconds of host threads in once-per-hit mode): hit planes, ray-tree hashes and colours
+    bit-exact, counters equal; the plain frame (the headline's kernel, render_kernel<..,2,..>, through the
+    asynchronous entry point) equals the debug frame."""
+    import torch
+    sc = water_scene if water else default_scene
+    f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, 3840, 2160)
+    rep = assert_parity(gfb, gpl, ofb, opl, f"config 3: 3840x2160 water={water}")
+    assert rep["exact_fraction"] == 1.0, rep
+    out = torch.zeros((2160, 3840), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.render_device(f, out.data_ptr())
+    gpu_ctx.sync()
+    assert gpu_ctx.kernel_name() == f"render_kernel<false,false,2,{'true' if water else 'false'}>"
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), gfb)
+    assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+
+
 def test_config3_water_4k_properties(gpu_ctx, water_scene):
     """BASELINE.json config 3 at its exact size (3840x2160, the water platform: reflection + refraction to depth 3):
     plain == debug on every pixel, bands == the full frame, the parts of a 3-way split reassemble, the unpainted
