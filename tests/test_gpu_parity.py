@@ -286,6 +286,15 @@ def test_config3_4k_against_the_oracle(gpu_ctx, oracle_mod, default_scene, water
     assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
 
 
+def test_config5_8k_against_the_oracle(gpu_ctx, oracle_mod, default_scene):
+    """BASELINE.json config 5's frame size, 7680x4320 (the orbit's first view), against the oracle on all 33 M pixels
+    (several seconds of host threads): hit planes, ray-tree hashes and colours bit-exact, counters equal."""
+    f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, default_scene, 7680, 4320)
+    rep = assert_parity(gfb, gpl, ofb, opl, "config 5: 7680x4320")
+    assert rep["exact_fraction"] == 1.0, rep
+    assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+
+
 def test_config3_water_4k_properties(gpu_ctx, water_scene):
     """BASELINE.json config 3 at its exact size (3840x2160, the water platform: reflection + refraction to depth 3):
     plain == debug on every pixel, bands == the full frame, the parts of a 3-way split reassemble, the unpainted
@@ -482,6 +491,19 @@ def test_bvh_depth_limit_falls_back_to_the_chunk_traversal(tuned_ctx, oracle_mod
     tuned_ctx.upload(scene)
     _, ex = tuned_ctx.count_executed(f)
     assert ex.bvh_steps > 0
+
+
+def test_config4_bands_of_the_4k_frame_against_the_oracle(gpu_ctx, oracle_mod):
+    """BASELINE.json config 4 at its exact size, 3840x2160: the whole frame is minutes of brute force for the oracle,
+    so two 32-row bands of it through the terrain (the same rays as in the
+    whole frame) are compared on every pixel: hit planes, ray-tree hashes, colours, counters."""
+    scene = rt.synthetic_scene()
+    for y0 in (1000, 1232):
+        f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, scene, 3840, 2160, y0=y0, y1=y0 + 32)
+        rep = assert_parity(gfb, gpl, ofb, opl, f"config 4: rows {y0}..{y0 + 32} of 3840x2160")
+        assert rep["exact_fraction"] == 1.0, rep
+        assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+        assert (gpl["hit_cube"] != rt.RT_NO_HIT).mean() > 0.1, y0
 
 
 def test_config4_plain_equals_debug_at_4k(gpu_ctx):
