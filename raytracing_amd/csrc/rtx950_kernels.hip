@@ -1534,13 +1534,18 @@ DEV Col light_term(const Params& P, uint32_t pass, uint32_t li, bool lit, bool h
     const float e_b = m_specular * __builtin_amdgcn_logf(cb);  // cb <= 0: NaN or -inf times y > 0
     const bool dark = (rr > 0.99f) && (rr < 1.01f) && (m_specular > 0.0f) &&
                       ((cb <= 0.0f) || ((cb < 1.0f) && (__builtin_amdgcn_exp2f(e_b) * (c_max * m_albedo1) < 0.98f)));
+    // (adding a black specular term and scaling by k_ds = 1 - 0 - 0 leave the whole numbers up to 255 of `diffuse` as
+    // they are: both are skipped where that holds for the whole wave - every matte surface away from a highlight)
+    Col ds = diffuse;
     if (wave_any(lit && !dark)) {
         const V3 reflect_dir = vnormalize(refl_raw);
         const float spec_i = powf_like_libm(rs_clamp(vdot(view_dir, reflect_dir), 0.0f, 1.0f), m_specular);
-        if (wave_any(!(spec_i < 0x1p-8f)))
+        if (wave_any(!(spec_i < 0x1p-8f))) {
             specular = col_mul(col_mul(col_mul(col_from_hex(L.color_0rgb), m_albedo1), spec_i), light_intensity);
+            ds = col_add(diffuse, specular);
+        }
     }
-    return col_mul(col_add(diffuse, specular), k_ds);
+    return wave_any(k_ds != 1.0f) ? col_mul(ds, k_ds) : ds;
 }
 
 // One pass of render.rs:298-312 (spheres with ambient 1, or cubes with ambient_light) for the wave's
@@ -1636,13 +1641,16 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
                 // the reference casts the secondary rays inside the light loop: without lights there are none
                 has_refl = hit_any && (k_r > 0.0f) && (nl != 0u);
                 has_refr = hit_any && (k_t > 0.0f) && (nl != 0u);
-                if (wave_any(has_refl || has_refr)) {
+                // each kind only where some lane of the wave has it (a mirror-like material has no refraction ray)
+                if (wave_any(has_refl)) {
                     refl_d = vnormalize(reflect(vneg(d), hit.n));
                     refl_o = vadd(hit.p, vscale(hit.n, 1e-2f));
+                }
+                if (wave_any(has_refr)) {
                     refr_d = refract(d, hit.n, m.ior);
                     refr_o = vadd(hit.p, vscale(hit.n, 1e-3f));
-                    if constexpr (COUNT) cnt.ev[EV_CHILD] += (has_refl || has_refr) ? 1u : 0u;
                 }
+                if constexpr (COUNT) cnt.ev[EV_CHILD] += (has_refl || has_refr) ? 1u : 0u;
                 PROF_MARK(PH_CHILDSETUP);
             }
             if constexpr (COUNT) {
@@ -1680,7 +1688,10 @@ DEV uint32_t trace_tree(const Params& P, uint32_t pass, bool active0, V3 o, V3 d
             if constexpr (ASYNC) {
                 if ((postbits >> depth) & 1u) sumf |= mail_collect(mb, depth);
             }
-            res = node_finish(P, sumf, k_r, k_t, has_refl ? P.sky : zero, has_refr ? P.sky : zero);
+            // (a wave without a child anywhere - every matte tile - adds 0 + 0 to light sums that are whole numbers
+            // up to 255 already: node_finish would return them unchanged)
+            if (wave_any(any_child)) res = node_finish(P, sumf, k_r, k_t, has_refl ? P.sky : zero, has_refr ? P.sky : zero);
+            else res = hit_any ? (sumf & 0x00FFFFFFu) : P.sky;
             if constexpr (DBG) res_h = hit_any ? hmix(hmix(h, has_refl ? kHashCut : 0u), has_refr ? kHashCut : 0u) : h;
             unwinding = true;
         }
