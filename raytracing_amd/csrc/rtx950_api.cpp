@@ -125,7 +125,7 @@ struct rt_ctx {
     size_t h_n_spheres = 0;
     uint32_t* d_cube_id = nullptr;
     uint32_t* d_cube_perm = nullptr;
-    BvhNode* d_bvh = nullptr;
+    BvhPair* d_bvh = nullptr;
     float* d_sphere_filt = nullptr;
     float* d_chunk_box = nullptr;
     float* d_cube_filt_list = nullptr;   // list-ordered stream for shadow queries of long lists (when compact)
@@ -1035,7 +1035,18 @@ int rt_scene_upload(rt_ctx* ctx, const rt_cube* cubes, size_t n_cubes, const rt_
     if ((rc = upload(ctx, &ctx->d_cube_filt_list, hf_list)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_cube_id_list, hid_list)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_chunk_box_list, hbox_list)) != RT_OK) return rc;
-    if ((rc = upload(ctx, &ctx->d_bvh, nodes)) != RT_OK) return rc;
+    std::vector<BvhPair> pairs(nodes.size() / 2);
+    for (size_t p = 0; p < pairs.size(); ++p)
+        for (int side = 0; side < 2; ++side) {
+            const BvhNode& nd = nodes[2 * p + side];
+            BvhPair& pr = pairs[p];
+            float* xy = side ? pr.b_xy : pr.a_xy;
+            float* hxy = side ? pr.b_hxy : pr.a_hxy;
+            xy[0] = nd.cx; xy[1] = nd.cy; hxy[0] = nd.hx; hxy[1] = nd.hy;
+            pr.cz[side] = nd.cz; pr.hz[side] = nd.hz;
+            pr.first_count[side] = nd.first_count; pr.link[side] = nd.link;
+        }
+    if ((rc = upload(ctx, &ctx->d_bvh, pairs)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_spheres, hs)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_sphere_meta, hsm)) != RT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_sphere_filt, hsf)) != RT_OK) return rc;

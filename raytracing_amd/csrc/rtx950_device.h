@@ -37,6 +37,16 @@ struct BvhNode {
     uint32_t link;         // inner node: index of the pair holding its children; leaf: the cube's id
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be two dwordx4");
+// The device reads a pair laid out for PACKED FMAs (cube_query_bvh): x and y of a box side by side, as the ray's
+// per-axis coefficients are (RayPre::r_xy ...), and the z components of the two boxes side by side, so that the slab
+// filter of both boxes is nine v_pk_fma_f32 with four splatted coefficients.
+struct BvhPair {
+    float a_xy[2], a_hxy[2];           // dwordx4 0: (a.cx, a.cy, a.hx, a.hy)
+    float b_xy[2], b_hxy[2];           // dwordx4 1: the same of box b
+    float cz[2], hz[2];                // dwordx4 2: (a.cz, b.cz, a.hz, b.hz)
+    uint32_t first_count[2], link[2];  // dwordx4 3
+};
+static_assert(sizeof(BvhPair) == 64, "BvhPair must be four dwordx4");
 
 // reference src/sphere.rs:10-15
 struct SphereRec {
@@ -85,7 +95,7 @@ struct Params {
     uint32_t shadow_list;
     uint32_t n_chunks;
     // every scene: cube_perm is valid (identity for short lists); bvh: long lists only (n_bvh_nodes = 0 otherwise)
-    const BvhNode* bvh;
+    const BvhPair* bvh;
     uint32_t n_bvh_nodes;
     float coherent_thr;  // a wave whose cull inflation (2 B dr + wr) exceeds this walks the BVH per lane
     const SphereRec* spheres;

@@ -787,12 +787,14 @@ struct QState {
 //                    among equals, which is how it is evaluated here in any visiting order.
 //   Q_SHADOW         render.rs:44-70: the passing cube with the lowest list index among those whose id
 //                    differs from the impact object's (render.rs:113); again in any visiting order.
-template <int MODE, bool UNIFORM>
+// SLAB: the caller has the cube's approximate interval already (cube_query_bvh: a leaf's box IS its cube, and
+// box_slab2's interval of it is cube_slab_approx's, operation for operation).
+template <int MODE, bool UNIFORM, bool SLAB = false>
 DEV void cube_candidate(const Params& P, const RayPre& q, bool active, bool any_zero, V3 o, V3 d, uint32_t impact_id, uint32_t i, uint32_t cid,
-                        float kx, float ky, float kz, float kh, QState& st PROF_ARG)
+                        float kx, float ky, float kz, float kh, QState& st PROF_ARG, float slab_lo = 0.0f, float slab_hi = 0.0f)
 {
-    float lo, hi;
-    cube_slab_approx(kx, ky, kz, kh, q, lo, hi);
+    float lo = slab_lo, hi = slab_hi;
+    if constexpr (!SLAB) cube_slab_approx(kx, ky, kz, kh, q, lo, hi);
     const float gap = lo - hi;
     bool live = active && !(gap > q.tol);  // not proven to miss
     if constexpr (MODE == Q_SHADOW) live = live && (i < st.blocker) && (cid != impact_id);
@@ -1037,25 +1039,35 @@ DEV uint32_t* bvh_stack(const Params& P)
     else return dyn_lds + ((threadIdx.x >> 6) % WAVES) * (P.bvh_levels * 64u);
 }
 
-struct BoxTest { float lo; bool hit; };
-DEV BoxTest box_slab(const RayPre& q, f32x4 c, f32x4 h)
+// The slab filter of the two sibling boxes of a pair at once, in nine packed FMAs: x and y of a box are a register
+// pair like the ray's per-axis coefficients, the z components of the two boxes are one (BvhPair).  Per box this is
+// cube_slab_approx's interval, operation for operation, with three half extents.
+struct BoxTest2 { float lo_a, hi_a, lo_b, hi_b; bool hit_a, hit_b; };
+DEV BoxTest2 box_slab2(const RayPre& q, f32x2 a_xy, f32x2 a_hxy, f32x2 b_xy, f32x2 b_hxy, f32x2 cz, f32x2 hz)
 {
-    const float mx = __builtin_fmaf(c[0], q.r_xy[0], q.c_xy[0]), my = __builtin_fmaf(c[1], q.r_xy[1], q.c_xy[1]);
-    const float mz = __builtin_fmaf(c[2], q.rc_z[0], q.rc_z[1]);
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(h[0], q.na_xy[0], mx), __builtin_fmaf(h[1], q.na_xy[1], my)),
-                                     __builtin_fmaf(h[2], q.a_z_pm[0], mz));
-    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaf(h[0], -q.na_xy[0], mx), __builtin_fmaf(h[1], -q.na_xy[1], my)),
-                                     __builtin_fmaf(h[2], q.a_z_pm[1], mz));
-    return BoxTest{lo, !(lo - hi > q.tol)};  // NaN -> hit
+    const f32x2 ma = __builtin_elementwise_fma(a_xy, q.r_xy, q.c_xy), mb = __builtin_elementwise_fma(b_xy, q.r_xy, q.c_xy);
+    const f32x2 mz = __builtin_elementwise_fma(cz, f32x2{q.rc_z[0], q.rc_z[0]}, f32x2{q.rc_z[1], q.rc_z[1]});
+    const f32x2 na = __builtin_elementwise_fma(a_hxy, q.na_xy, ma), fa = __builtin_elementwise_fma(a_hxy, -q.na_xy, ma);
+    const f32x2 nb = __builtin_elementwise_fma(b_hxy, q.na_xy, mb), fb = __builtin_elementwise_fma(b_hxy, -q.na_xy, mb);
+    const f32x2 nz = __builtin_elementwise_fma(hz, f32x2{q.a_z_pm[0], q.a_z_pm[0]}, mz);
+    const f32x2 fz = __builtin_elementwise_fma(hz, f32x2{q.a_z_pm[1], q.a_z_pm[1]}, mz);
+    BoxTest2 t;
+    t.lo_a = __builtin_fmaxf(__builtin_fmaxf(na[0], na[1]), nz[0]);
+    t.hi_a = __builtin_fminf(__builtin_fminf(fa[0], fa[1]), fz[0]);
+    t.lo_b = __builtin_fmaxf(__builtin_fmaxf(nb[0], nb[1]), nz[1]);
+    t.hi_b = __builtin_fminf(__builtin_fminf(fb[0], fb[1]), fz[1]);
+    t.hit_a = !(t.lo_a - t.hi_a > q.tol);  // NaN -> hit
+    t.hit_b = !(t.lo_b - t.hi_b > q.tol);
+    return t;
 }
 // A direction component that is exactly zero does not constrain the filter's interval (ray_pre), but the
 // reference's test fails for every cube whose slab on that axis does not hold the origin (zero_axis_check):
 // a box whose slab the origin misses by more than zdelta holds no cube that passes.
-DEV bool box_zero_axis_miss(const RayPre& q, V3 o, f32x4 c, f32x4 h)
+DEV bool box_zero_axis_miss(const RayPre& q, V3 o, float cx, float cy, float cz, float hx, float hy, float hz)
 {
     const bool zx = (q.zbits & 1u) != 0u, zy = (q.zbits & 2u) != 0u, zz = (q.zbits & 4u) != 0u;
-    return (zx && __builtin_fabsf(c[0] - o.x) > h[0] + q.zdelta) || (zy && __builtin_fabsf(c[1] - o.y) > h[1] + q.zdelta) ||
-           (zz && __builtin_fabsf(c[2] - o.z) > h[2] + q.zdelta);
+    return (zx && __builtin_fabsf(cx - o.x) > hx + q.zdelta) || (zy && __builtin_fabsf(cy - o.y) > hy + q.zdelta) ||
+           (zz && __builtin_fabsf(cz - o.z) > hz + q.zdelta);
 }
 
 template <int MODE, uint32_t WAVES>
@@ -1080,41 +1092,49 @@ DEV void cube_query_bvh(const Params& P, const RayPre& q, bool active, V3 o, V3 
         // address register and no 64-bit arithmetic per step (10k-cube world -1.2 %)
         const uint32_t off = on ? pair * 64u : 0u;
         const f32x4* pn = (const f32x4*)((const char*)nodes + off);
-        const f32x4 ac = pn[0], ah = pn[1], bc = pn[2], bh = pn[3];
-        const float ac3 = ac[3], ah3 = ah[3], bc3 = bc[3], bh3 = bh[3];  // scalar copies first: see the note at u2f
-        const uint32_t fca = __builtin_bit_cast(uint32_t, ac3), fcb = __builtin_bit_cast(uint32_t, bc3);
-        const uint32_t link_a = __builtin_bit_cast(uint32_t, ah3), link_b = __builtin_bit_cast(uint32_t, bh3);
+        const f32x4 n0 = pn[0], n1 = pn[1], n2 = pn[2], n3 = pn[3];  // BvhPair: the two boxes interleaved by component
+        const float w0 = n3[0], w1 = n3[1], w2 = n3[2], w3 = n3[3];  // scalar copies first: see the note at u2f
+        const uint32_t fca = __builtin_bit_cast(uint32_t, w0), fcb = __builtin_bit_cast(uint32_t, w1);
+        const uint32_t link_a = __builtin_bit_cast(uint32_t, w2), link_b = __builtin_bit_cast(uint32_t, w3);
         const uint32_t cnt_a = fca & 7u, cnt_b = fcb & 7u, first_a = fca >> 3, first_b = fcb >> 3;
-        const BoxTest ta = box_slab(q, ac, ah), tb = box_slab(q, bc, bh);
-        bool meet_a = on && ta.hit, meet_b = on && tb.hit;
+        const f32x2 a_xy = f32x2{n0[0], n0[1]}, a_hxy = f32x2{n0[2], n0[3]}, b_xy = f32x2{n1[0], n1[1]}, b_hxy = f32x2{n1[2], n1[3]};
+        const f32x2 cz = f32x2{n2[0], n2[1]}, hz = f32x2{n2[2], n2[3]};
+        const BoxTest2 t = box_slab2(q, a_xy, a_hxy, b_xy, b_hxy, cz, hz);
+        bool meet_a = on && t.hit_a, meet_b = on && t.hit_b;
         if (any_zero) {
-            meet_a = meet_a && !box_zero_axis_miss(q, o, ac, ah);
-            meet_b = meet_b && !box_zero_axis_miss(q, o, bc, bh);
+            meet_a = meet_a && !box_zero_axis_miss(q, o, a_xy[0], a_xy[1], cz[0], a_hxy[0], a_hxy[1], hz[0]);
+            meet_b = meet_b && !box_zero_axis_miss(q, o, b_xy[0], b_xy[1], cz[1], b_hxy[0], b_hxy[1], hz[1]);
         }
         if constexpr (MODE == Q_SHADOW) {
             meet_a = meet_a && !(cnt_a == 0u && first_a >= st.blocker);
             meet_b = meet_b && !(cnt_b == 0u && first_b >= st.blocker);
         } else if constexpr (MODE == Q_NEAREST) {
             const float limit = st.b1 + 2.0f * q.tol;
-            meet_a = meet_a && !(ta.lo > limit);
-            meet_b = meet_b && !(tb.lo > limit);
+            meet_a = meet_a && !(t.lo_a > limit);
+            meet_b = meet_b && !(t.lo_b > limit);
         } else {
-            meet_a = meet_a && !(ta.lo - q.tol > st.best);
-            meet_b = meet_b && !(tb.lo - q.tol > st.best);
+            meet_a = meet_a && !(t.lo_a - q.tol > st.best);
+            meet_b = meet_b && !(t.lo_b - q.tol > st.best);
         }
         const bool leaf_a = meet_a && (cnt_a != 0u), leaf_b = meet_b && (cnt_b != 0u);
         PROF_MARK(PH_CULL);
         // a leaf IS its cube (centre, half size, list index and id in the node): no further fetch
-        if (wave_any(leaf_a))
-            cube_candidate<MODE, false>(P, q, leaf_a, any_zero, o, d, impact_id, first_a, link_a, ac[0], ac[1], ac[2], ah[0], st PROF_PASS);
-        if (wave_any(leaf_b))
-            cube_candidate<MODE, false>(P, q, leaf_b, any_zero, o, d, impact_id, first_b, link_b, bc[0], bc[1], bc[2], bh[0], st PROF_PASS);
+        // lanes with one leaf among the two share one evaluation (each takes its own leaf's values); a second one
+        // only when some lane has two
+        if (wave_any(leaf_a || leaf_b)) {
+            const bool ua = leaf_a;
+            cube_candidate<MODE, false, true>(P, q, leaf_a || leaf_b, any_zero, o, d, impact_id, ua ? first_a : first_b, ua ? link_a : link_b,
+                                              ua ? a_xy[0] : b_xy[0], ua ? a_xy[1] : b_xy[1], ua ? cz[0] : cz[1], ua ? a_hxy[0] : b_hxy[0], st PROF_PASS,
+                                              ua ? t.lo_a : t.lo_b, ua ? t.hi_a : t.hi_b);
+            if (wave_any(leaf_a && leaf_b))
+                cube_candidate<MODE, false, true>(P, q, leaf_a && leaf_b, any_zero, o, d, impact_id, first_b, link_b, b_xy[0], b_xy[1], cz[1], b_hxy[0], st PROF_PASS, t.lo_b, t.hi_b);
+        }
         PROF_MARK(PH_CAND);
         // inner children that are still worth a visit: the nearer / lower-indexed one next, the other deferred
         const bool in_a = meet_a && (cnt_a == 0u), in_b = meet_b && (cnt_b == 0u);
         bool a_first;
         if constexpr (MODE == Q_SHADOW) a_first = !(first_b < first_a);
-        else a_first = !(tb.lo < ta.lo);
+        else a_first = !(t.lo_b < t.lo_a);
         const bool both = in_a && in_b;
         if (both) stack[sp * 64u] = a_first ? link_b : link_a;
         const bool pop = on && !(in_a || in_b) && (sp != 0u);
