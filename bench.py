@@ -539,7 +539,7 @@ def main():
                         ctxs[i % len(ctxs)].render_device(f2, o2[i % len(ctxs)].data_ptr())
                     for c in ctxs:
                         c.sync()
-                n_warm, n_timed = (10, 40) if name == "synthetic_4k" else (30, 120)
+                n_warm, n_timed = (20, 100) if name == "synthetic_4k" else (30, 120)  # about 0.1 s each
                 frames2(n_warm)
                 for c in ctxs:
                     c.enable_timing(4)
