@@ -457,6 +457,39 @@ def test_shuffled_long_list(tuned_ctx, oracle_mod):
         assert tuned_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
 
 
+@pytest.mark.parametrize("scale", [0.0, 1.0, 1e9])
+def test_long_list_with_duplicate_cubes(tuned_ctx, oracle_mod, scale):
+    """Exact duplicates in a long list: in the Morton order two equal cubes are neighbours, so they end up as the two
+    LEAVES of one pair record, and a ray that meets one meets both - the walk's second leaf evaluation of a step, the
+    contested nearest hit (equal distances: the lowest list index wins, src/render.rs:94-101) and the shadow rule
+    (lowest index with a different id, src/render.rs:44-70, :113) all in one scene.  A third of the copies keep the
+    original's id (excluded together with it), the others get a new one; some copies are a little larger (overlap
+    without equality).  Each traversal forced for every wave, and the library's own choice."""
+    from raytracing_amd._ffi import Camera, Cube, Vec3
+    base = rt.synthetic_scene(n_cubes=420, n_spheres=6)
+    rng = np.random.default_rng(11)
+    cubes = [base.cubes[i] for i in range(len(base.cubes))]
+    copies = []
+    for i, c in enumerate(cubes):
+        k = Cube()
+        k.id = c.id if i % 3 == 0 else 100000 + i
+        k.center = c.center
+        k.size = c.size * (1.25 if i % 7 == 0 else 1.0)
+        k.material = base.cubes[int(rng.integers(len(cubes)))].material
+        copies.append(k)
+    order = rng.permutation(len(copies))
+    cubes = cubes + [copies[int(j)] for j in order]
+    spheres = [base.spheres[i] for i in range(len(base.spheres))]
+    cam = Camera(Vec3(3.0, 5.0, 12.0), Vec3(0.0, -2.0, 0.0), Vec3(0.0, 1.0, 0.0))  # close to the small terrain, looking down on it
+    sc = rt.make_scene(cubes, spheres, list(base.materials), list(base.lights), cam, base.ambient_light, base.sky_0rgb, base.atlas)
+    tuned_ctx.set_tuning(rt.RT_TUNE_COHERENT_SCALE, scale)
+    f, gfb, gpl, ofb, opl, ocnt = _both(tuned_ctx, oracle_mod, sc, 192, 108)
+    assert_parity(gfb, gpl, ofb, opl, f"long list with duplicates, coherent scale {scale}")
+    assert tuned_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+    hc = gpl["hit_cube"]
+    assert (hc != rt.RT_NO_HIT).mean() > 0.15 and (hc[hc != rt.RT_NO_HIT] >= 420).any()  # copies win where they are larger
+
+
 @pytest.mark.parametrize("dark,scale", [(-1, 1.0), (0, 1.0), (1, 1.0), (-1, 0.0), (-1, 1e9)])
 def test_config4_world_at_size(tuned_ctx, oracle_mod, dark, scale):
     """BASELINE.json config 4 at its size - 10 000 cubes (157 chunks: three 64-chunk groups of the chunk
