@@ -318,7 +318,7 @@ int rt_host_free(void* ptr);
 /* Allocation-free variant of rt_render_device, for callers that cannot call hipMalloc: code under HIP graph
  * capture, tight serving loops, harnesses that forbid allocation.  NO COUNTERPART in the reference.  Same
  * kernels and same output as rt_render_device, but the launches' work buffers (tile stamps, tile queue, tile
- * costs) live in one fixed array per GPU inside the library (5.8 MB, held until the process ends) instead of
+ * costs) live in one fixed array per GPU inside the library (6.4 MB, held until the process ends) instead of
  * buffers the context allocates and grows; the call performs no hipMalloc/hipFree, creates no events and takes
  * no timing samples.  Frames of more than RT_NOALLOC_MAX_TILES 8x8 tiles are refused with RT_ERR_LIMIT.  Every
  * call on a GPU, from any context, shares that GPU's array: the array keeps the last call's contents (the

@@ -73,10 +73,10 @@ struct WfScratch {
 
 // ---- the allocation-free entry point's work buffers (rt_render_device_noalloc) -------------------------
 // One array per GPU, held until the process ends: queue (64 + 9 x tiles words), stamps (64 + tiles + coarse
-// words) and tile costs (tiles + 1 words) for frames of up to RT_NOALLOC_MAX_TILES 8x8 tiles (5.8 MB).
+// words) and tile costs (tiles + 1 words) for frames of up to RT_NOALLOC_MAX_TILES 8x8 tiles (6.4 MB).
 constexpr size_t kNaTiles = RT_NOALLOC_MAX_TILES;
 constexpr size_t kNaQueueWords = kQueueBase + (kCostClasses + 1) * kNaTiles;
-constexpr size_t kNaStampWords = kStampBase + kNaTiles + kNaTiles / 16 + 64;  // coarse level: <= tiles/64 + (tiles_x + tiles_y)/8 + 1
+constexpr size_t kNaStampWords = kStampBase + 2 * (kNaTiles + kNaTiles / 16 + 64);  // two planes (cubes, spheres); coarse level: <= tiles/64 + (tiles_x + tiles_y)/8 + 1
 constexpr size_t kNaCostWords = kNaTiles + 64;
 constexpr size_t kNaWords = kNaQueueWords + kNaStampWords + kNaCostWords;
 static __device__ __align__(256) uint32_t scratch[kNaWords];
@@ -384,6 +384,7 @@ bool projection_setup(const Params& p, TileParams& t)
         mag = std::max(mag, std::fabs(t.eye[k]));
     }
     mag = std::max(mag, (double)p.bound_max);
+    if (p.n_spheres != 0u && std::isfinite(p.sphere_bound_max)) mag = std::max(mag, (double)p.sphere_bound_max);
     const double* r = t.right; const double* u = t.up; const double* f = t.fwd;
     const double det = r[0] * (u[1] * f[2] - u[2] * f[1]) - r[1] * (u[0] * f[2] - u[2] * f[0]) + r[2] * (u[0] * f[1] - u[1] * f[0]);
     if (!(std::fabs(det) > 0.5 && std::fabs(det) < 2.0)) regular = false;  // an orthonormal basis has |det| = 1
@@ -418,6 +419,7 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint
 {
     if (out_classified) *out_classified = false;
     p.tile_stamps = nullptr;
+    p.sphere_stamps = nullptr;
     p.tiles_x = (p.width + 7u) / 8u;
     p.tiles_y = (p.height + 7u) / 8u;
     p.frame_id = 0u;
@@ -430,7 +432,9 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint
     const size_t n_tiles = (size_t)p.grid_tx * p.grid_ty;
     const size_t qwords = kQueueBase + (kCostClasses + 1) * n_tiles;
     // fine stamps per 8x8 tile of the FRAME, then coarse stamps per block of 8x8 tiles
-    const size_t swords = kStampBase + (size_t)p.tiles_x * p.tiles_y + (size_t)((p.tiles_x + 7u) / 8u) * ((p.tiles_y + 7u) / 8u);
+    // ... for the cubes, and the same two levels once more for the spheres
+    const size_t plane_words = (size_t)p.tiles_x * p.tiles_y + (size_t)((p.tiles_x + 7u) / 8u) * ((p.tiles_y + 7u) / 8u);
+    const size_t swords = kStampBase + 2 * plane_words;
     int rc;
     // a fresh buffer is all zero: both queue header banks, "unknown" tile costs, no stamps
     if ((rc = grow(ctx, ts, &ts.queue, &ts.queue_cap, qwords, "queue entries")) != RT_OK) return rc;
@@ -462,6 +466,12 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint
     }
     t.cube_filt = p.cube_filt;
     t.n_cubes = p.n_cubes;
+    // spheres are classified when the cull can bound them (Params::sphere_ok); otherwise their pass is traced everywhere
+    const bool classify_spheres = p.n_spheres != 0u && p.sphere_ok != 0u && std::isfinite(p.sphere_bound_max) && std::isfinite(p.sphere_grow);
+    t.sphere_filt = p.sphere_filt;
+    t.n_spheres = classify_spheres ? p.n_spheres : 0u;
+    t.sphere_grow = (double)p.sphere_grow;
+    t.sphere_stamps = ts.stamps + kStampBase + plane_words;
     t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y;
     t.queue = ts.queue;
     t.qsel = p.qsel;
@@ -477,6 +487,7 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint
     hipError_t e = (hipError_t)launch_classify(t, (void*)ctx->stream);  // also zeroes the next header bank
     if (e != hipSuccess) return fail_hip(ctx, e, "classify kernel launch");
     p.tile_stamps = ts.stamps;
+    p.sphere_stamps = classify_spheres ? t.sphere_stamps : nullptr;
     p.frame_id = ts.frame_id;
     if (out_classified) *out_classified = true;
     return RT_OK;

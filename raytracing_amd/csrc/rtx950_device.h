@@ -119,6 +119,9 @@ struct Params {
     // frame_id: some cube's padded projection touches the 8x8 pixel tile (tx, ty) of the frame.  After the
     // tiles_x * tiles_y fine words: one coarse word per block of 8x8 tiles, used by large projections.
     const uint32_t* tile_stamps;
+    // the same two levels for the spheres (no header word of its own: word 0 of tile_stamps covers both); null: the
+    // sphere pass of a scene with spheres is traced for every tile
+    const uint32_t* sphere_stamps;
     uint32_t tiles_x, tiles_y;
     uint32_t frame_id;
     // Work queue of this launch (build_queue -> render_kernel): two header banks of 16
@@ -206,6 +209,13 @@ constexpr uint32_t kHeavyGrid = 576;       // workgroups of render_heavy_kernel 
 struct TileParams {
     const float* cube_filt;  // (centre.xyz, half size) per cube
     uint32_t n_cubes;
+    // spheres are classified like cubes, by the bounding box of the sphere grown as in sphere_query (the reference's
+    // f32 discriminant can report a hit for a line that misses by a little): blocks n_cubes .. n_cubes + n_spheres - 1
+    // stamp the sphere plane.  n_spheres == 0: no sphere plane (no spheres, or a sphere list the cull cannot bound).
+    const float* sphere_filt;  // (centre.xyz, |radius|) per sphere
+    uint32_t n_spheres;
+    double sphere_grow;        // Params::sphere_grow
+    uint32_t* sphere_stamps;   // the sphere plane: per-tile words, then the coarse level (no header of its own)
     double eye[3], right[3], up[3], fwd[3];
     double inv_det;          // 1 / det[right up fwd]
     double pad;              // absolute padding of every cube bound

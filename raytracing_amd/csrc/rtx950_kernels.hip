@@ -1409,7 +1409,9 @@ DEV float shadow_query(const Params& P, uint32_t pass, bool active, V3 origin, V
 //    instruction cache - and several hundred spilled registers.)
 // Frame of a node waiting for its children, per lane:
 enum { F_RO = 0, F_RD = 3, F_SUMF = 6, F_C0 = 7, F_KR = 8, F_KT = 9, F_H = 10, F_H0 = 11 };
-constexpr uint32_t kEntryNoCubes = 1u << 15;  // queue entry flag: the tile's cube pass is answered without tracing
+constexpr uint32_t kEntryNoCubes = 1u << 15;    // queue entry flag: the tile's cube pass is answered without tracing
+constexpr uint32_t kEntryNoSpheres = 1u << 14;  // ... and its sphere pass (no sphere's grown box projects into the tile)
+constexpr uint32_t kEntryColMask = 0x3FFFu;     // tile column (frames are at most 65 536 wide: 8 192 columns)
 constexpr uint32_t kPaintGroup = 16;  // untraced tiles painted per surplus workgroup
 constexpr int kStackDepth = 3;  // nodes at depth 0..2 can wait for traced children (max_depth <= 3)
 template <bool DBG, int SPLIT = 0>
@@ -1778,19 +1780,30 @@ DEV uint32_t tile_y0(const Params& P, uint32_t by) { return P.y0 + ((by >> 1) * 
 
 // No cube's projection touches the tile (classify_tiles)?  The render tile is aligned to the band
 // start y0, so it can straddle two rows of the frame-aligned classification tiles.  Wave-uniform.
-DEV bool tile_has_no_cubes(const Params& P, uint32_t bx, uint32_t ty0)
+// `plane`: the fine words of the cubes' or the spheres' stamps, the coarse level behind them.
+DEV bool tile_plane_clear(const Params& P, const uint32_t* plane, uint32_t bx, uint32_t ty0)
 {
-    if (!P.tile_stamps) return false;
     const uint32_t last = P.tiles_y - 1u;
     const uint32_t r0 = (ty0 >> 3) < last ? (ty0 >> 3) : last;
     const uint32_t r1 = ((ty0 + 7u) >> 3) < last ? ((ty0 + 7u) >> 3) : last;
-    const uint32_t* st = P.tile_stamps;
-    const uint32_t s_all = st[0], s0 = st[kStampBase + r0 * P.tiles_x + bx], s1 = st[kStampBase + r1 * P.tiles_x + bx];
-    // coarse level: blocks of 8x8 tiles, stamped instead of the tiles by cubes with a large projection
-    const uint32_t* cs = st + kStampBase + P.tiles_x * P.tiles_y;
+    const uint32_t s_all = P.tile_stamps[0], s0 = plane[r0 * P.tiles_x + bx], s1 = plane[r1 * P.tiles_x + bx];
+    // coarse level: blocks of 8x8 tiles, stamped instead of the tiles by objects with a large projection
+    const uint32_t* cs = plane + P.tiles_x * P.tiles_y;
     const uint32_t ctx = (P.tiles_x + 7u) >> 3;
     const uint32_t c0 = cs[(r0 >> 3) * ctx + (bx >> 3)], c1 = cs[(r1 >> 3) * ctx + (bx >> 3)];
     return (s_all != P.frame_id) && (s0 != P.frame_id) && (s1 != P.frame_id) && (c0 != P.frame_id) && (c1 != P.frame_id);
+}
+DEV bool tile_has_no_cubes(const Params& P, uint32_t bx, uint32_t ty0)
+{
+    if (!P.tile_stamps) return false;
+    return tile_plane_clear(P, P.tile_stamps + kStampBase, bx, ty0);
+}
+// a scene without spheres has an empty sphere pass everywhere; one with spheres only where no sphere projects
+DEV bool tile_has_no_spheres(const Params& P, uint32_t bx, uint32_t ty0)
+{
+    if (P.n_spheres == 0u) return true;
+    if (!P.tile_stamps || !P.sphere_stamps) return false;
+    return tile_plane_clear(P, P.sphere_stamps, bx, ty0);
 }
 
 // build_queue: one thread per tile of the launch appends the tile to one of the queue's lists.  A
@@ -1809,7 +1822,8 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
     const uint32_t ty0 = tile_y0(P, by);
     const bool in_band = valid && (ty0 < P.y1);
     const bool no_cubes = tile_has_no_cubes(P, bx, ty0);
-    const bool traced = in_band && ((P.n_spheres != 0u) || !no_cubes);
+    const bool no_spheres = tile_has_no_spheres(P, bx, ty0);
+    const bool traced = in_band && !(no_spheres && no_cubes);
     // cost class from the tile's cycle count in the previous launch: < 8K cycles -> 0, then one class per
     // doubling, >= 512K -> 7
     const uint32_t cost = valid ? P.tile_cost[t] : 0u;
@@ -1849,7 +1863,7 @@ __global__ __launch_bounds__(1024) void build_queue(const Params P)
             base_cls[threadIdx.x] = n_cls[threadIdx.x] ? atomicAdd(&P.queue[(P.qsel ^ 1u) * 16u + kHeavyCountWord], n_cls[threadIdx.x]) : 0u;
     }
     __syncthreads();
-    if (listed) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (no_cubes ? kEntryNoCubes : 0u) | (by << 16);
+    if (listed) P.queue[kQueueBase + cls * tiles + base_cls[cls] + rank] = bx | (no_cubes ? kEntryNoCubes : 0u) | (no_spheres ? kEntryNoSpheres : 0u) | (by << 16);
     if (HEAVY && heavy_next) {
         const uint32_t slot = base_cls[kCostClasses + 1u] + hrank;
         if (slot < kHeavyCap) {  // a longer list is cut: the tiles beyond it stay with render_kernel (no mark)
@@ -1943,7 +1957,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ?
             const uint32_t px_hash = hmix(hmix(kHashBasis, no_hash), no_hash);
             for (uint32_t j = idx * kPaintGroup; j < n_sky && j < (idx + 1u) * kPaintGroup; ++j) {
                 const uint32_t e = sky_list[j];
-                const uint32_t bx = e & 0x7FFFu, by = e >> 16;
+                const uint32_t bx = e & kEntryColMask, by = e >> 16;
                 const uint32_t x = bx * 8u + (lane & 7u), y = tile_y0(P, by) + (lane >> 3);
                 if (x < P.width && y < P.y1) {
                     const size_t i_band = (size_t)(by * 8u + (lane >> 3)) * P.width + x;
@@ -1956,9 +1970,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ?
                         if (P.hit_sphere) P.hit_sphere[i_band] = kNoHit;
                         if (P.tree_hash) P.tree_hash[i_band] = px_hash;
                     }
-                    if constexpr (COUNT) {  // one nearest-hit walk of the (empty) sphere list, one of the cube list
+                    if constexpr (COUNT) {  // one nearest-hit walk of the sphere list, one of the cube list
                         cnt.v[0] += 2ull; cnt.v[5] += 2ull;
                         cnt.v[2] += P.n_cubes; cnt.v[7] += P.n_cubes;
+                        cnt.v[3] += P.n_spheres; cnt.v[8] += P.n_spheres;
                     }
                 }
             }
@@ -1972,7 +1987,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ?
         const V3 up = v3(P.up[0], P.up[1], P.up[2]);
         const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
         const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
-        const uint32_t bx = entry & 0x7FFFu, by = entry >> 16;
+        const uint32_t bx = entry & kEntryColMask, by = entry >> 16;
         const uint32_t ty0 = tile_y0(P, by);
         const uint32_t x = bx * 8u + (lane & 7u);
         const uint32_t y = ty0 + (lane >> 3);
@@ -1983,7 +1998,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ?
         // render.rs:298-312: a spheres-only pass with ambient 1, a cubes-only pass with ambient_light; the
         // sphere colour wins unless it equals the sky colour.  Passes that cannot hit anything are not
         // traced (wave-uniform): no spheres at all, or no cube projecting into the tile.
-        const bool skip_s = (P.n_spheres == 0u);
+        const bool skip_s = (P.n_spheres == 0u) || ((entry & kEntryNoSpheres) != 0u);  // no spheres, or none projects into the tile
         const bool skip_c = (entry & kEntryNoCubes) != 0u;  // no cube projects into the tile (classification)
         V3 dir = v3(0.0f, 0.0f, 0.0f);
         if (!(skip_s && skip_c)) {
@@ -2005,9 +2020,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ?
                 hi = kNoHit;
                 hh = hmix(kHashBasis, kNoHit);
                 if constexpr (COUNT) {  // the reference still walks the list for this ray
-                    const unsigned long long one = active ? 1ull : 0ull, tests = (pass == PASS_CUBES && active) ? P.n_cubes : 0ull;
+                    const unsigned long long one = active ? 1ull : 0ull;
+                    const unsigned long long tests = active ? (pass == PASS_CUBES ? P.n_cubes : P.n_spheres) : 0ull;
+                    const int slot = (pass == PASS_CUBES) ? 2 : 3;  // cube_tests / sphere_tests
                     cnt.v[0] += one; cnt.v[5] += one;
-                    cnt.v[2] += tests; cnt.v[7] += tests;
+                    cnt.v[slot] += tests; cnt.v[5 + slot] += tests;
                 }
             } else {
                 const Mailbox none{nullptr, nullptr, nullptr};
@@ -2076,7 +2093,7 @@ DEV void plain_tile(const Params& P, uint32_t entry, uint32_t* stk, const Mailbo
     const V3 up = v3(P.up[0], P.up[1], P.up[2]);
     const V3 fwd = v3(P.fwd[0], P.fwd[1], P.fwd[2]);
     const V3 eye = v3(P.eye[0], P.eye[1], P.eye[2]);
-    const uint32_t bx = entry & 0x7FFFu, by = entry >> 16;
+    const uint32_t bx = entry & kEntryColMask, by = entry >> 16;
     const uint32_t ty0 = tile_y0(P, by);
     const uint32_t x = bx * 8u + (lane & 7u);
     const uint32_t y = ty0 + (lane >> 3);
@@ -2197,13 +2214,13 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(R
         // an entry outside the launch's tile grid cannot come from this launch's list (a gate that gave up lets
         // the kernel start before the list is whole): skipped by every wave alike, and counted as finished
         const uint32_t raw = list[item];
-        if ((raw & 0x7FFFu) >= P.grid_tx || (raw >> 16) >= P.grid_ty) {
+        if ((raw & kEntryColMask) >= P.grid_tx || (raw >> 16) >= P.grid_ty) {
             if (threadIdx.x == 0u) __hip_atomic_fetch_add(&P.queue[P.qsel * 16u + kHeavyDoneWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
         ++items;
         if (wave == 0u) {
-            const uint32_t entry = raw & ~kEntryNoCubes;
+            const uint32_t entry = raw & ~(kEntryNoCubes | kEntryNoSpheres);
 #ifdef RTX_PROFILE
             const uint32_t prof_c0 = (uint32_t)__builtin_readcyclecounter();
             if (threadIdx.x == 0u) { ctl.prof_wait = 0u; for (uint32_t w = 0; w < kShaders; ++w) { ctl.prof_busy[w] = 0u; ctl.prof_nodes[w] = 0u; } }
@@ -2211,7 +2228,7 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(R
             plain_tile<LARGE, DARK, true>(P, entry, stk, mb, kHeavyCostScale);
 #ifdef RTX_PROFILE
             if (threadIdx.x == 0u && P.counters) {
-                uint32_t* slot = (uint32_t*)P.counters + 64 + ((size_t)(entry >> 16) * P.grid_tx + (entry & 0x7FFFu)) * 40u;
+                uint32_t* slot = (uint32_t*)P.counters + 64 + ((size_t)(entry >> 16) * P.grid_tx + (entry & kEntryColMask)) * 40u;
                 slot[0] = (uint32_t)__builtin_readcyclecounter() - prof_c0;
                 slot[1] = ctl.prof_wait;
                 for (uint32_t w = 0; w < kShaders; ++w) { slot[2 + w] = ctl.prof_busy[w]; slot[4 + w] = ctl.prof_nodes[w]; }
@@ -2365,7 +2382,7 @@ DEV WfItem wf_load_item(const WfItem* base, uint32_t i)
 DEV void wf_mark_redo(const Params& P, const WfParams& W, uint32_t entry)
 {
     if ((threadIdx.x & 63u) == 0u) {
-        const uint32_t t = (entry >> 16) * P.grid_tx + (entry & 0x7FFFu);
+        const uint32_t t = (entry >> 16) * P.grid_tx + (entry & kEntryColMask);
         if (atomicExch(&W.redo_mark[t], W.seq) != W.seq) {
             const uint32_t slot = atomicAdd(&W.header[kWfRedoBase], 1u);
             W.header[kWfRedoBase + kQueueBase + slot] = entry;  // at most one entry per tile of the launch
@@ -2462,12 +2479,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LARGE == 1 ?
                 idx -= found ? 0u : n_k;
             }
             if (!found) break;  // plain frames list no paint-only tiles (build_queue paints them)
-            const uint32_t bx = entry & 0x7FFFu, by = entry >> 16;
+            const uint32_t bx = entry & kEntryColMask, by = entry >> 16;
             const uint32_t x = bx * 8u + (lane & 7u);
             const uint32_t y = tile_y0(P, by) + (lane >> 3);
             const bool active = (x < P.width) && (y < P.y1);
             // a pass that cannot hit anything is not traced: its root stays "no hit" (the sky colour)
-            const bool skip = (pass == PASS_SPHERES) ? (P.n_spheres == 0u) : ((entry & kEntryNoCubes) != 0u);
+            const bool skip = (pass == PASS_SPHERES) ? ((P.n_spheres == 0u) || ((entry & kEntryNoSpheres) != 0u)) : ((entry & kEntryNoCubes) != 0u);
             WfNode n;
             n.sumf = 0u; n.mat = 0u; n.face = 0u; n.has_refl = false; n.has_refr = false;
             uint32_t fc = 0u, nc = 0u;
@@ -2608,7 +2625,7 @@ __global__ __launch_bounds__(64) void wf_combine_kernel(const Params P, const Wf
             if (pass == PASS_SPHERES) px = c;
             else px = (px == P.sky) ? c : px;
         }
-        const uint32_t bx = entry & 0x7FFFu, by = entry >> 16;
+        const uint32_t bx = entry & kEntryColMask, by = entry >> 16;
         const uint32_t x = bx * 8u + (lane & 7u);
         const uint32_t y = tile_y0(P, by) + (lane >> 3);
         const uint32_t out_row = by * 8u + (lane >> 3);
@@ -2660,9 +2677,15 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
             if (lane < 16u) T.wf_header[kWfRedoBase + lane] = 0u;
         }
     }
-    if (cube >= T.n_cubes) return;
-    const float* rec = T.cube_filt + (size_t)cube * 4u;
-    const double h = __builtin_fabs((double)rec[3]) + T.pad;
+    if (cube >= T.n_cubes + T.n_spheres) return;
+    // blocks behind the cubes: the spheres, as the bounding box of the sphere grown by sphere_grow / r (sphere_query:
+    // how far a line can miss and still be reported by the reference's f32 discriminant); r -> 0 gives an infinite
+    // box, which cannot be projected: everything is traced
+    const bool is_sphere = cube >= T.n_cubes;
+    const float* rec = is_sphere ? T.sphere_filt + (size_t)(cube - T.n_cubes) * 4u : T.cube_filt + (size_t)cube * 4u;
+    const double h0 = __builtin_fabs((double)rec[3]);
+    const double h = (is_sphere ? h0 + T.sphere_grow / h0 : h0) + T.pad;
+    uint32_t* plane = is_sphere ? T.sphere_stamps : T.stamps + kStampBase;  // fine words, then the coarse level
     double q[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) q[k] = (double)rec[k] + (((lane >> k) & 1u) ? h : -h) - T.eye[k];
@@ -2698,11 +2721,11 @@ __global__ __launch_bounds__(64) void classify_tiles(const TileParams T)
     if (n <= 1024u) {
         for (uint32_t i = lane; i < n; i += 64u) {
             const uint32_t tx = tx0 + i % nx, ty = ty0 + i / nx;
-            T.stamps[kStampBase + (size_t)ty * T.tiles_x + tx] = T.frame_id;
+            plane[(size_t)ty * T.tiles_x + tx] = T.frame_id;
         }
     } else {
         // a large projection (a cube near the eye): stamp blocks of 8x8 tiles instead, 64x fewer stores
-        uint32_t* cs = T.stamps + kStampBase + (size_t)T.tiles_x * T.tiles_y;
+        uint32_t* cs = plane + (size_t)T.tiles_x * T.tiles_y;
         const uint32_t ctx = (T.tiles_x + 7u) >> 3;
         const uint32_t cx0 = tx0 >> 3, cy0 = ty0 >> 3, cnx = (tx1 >> 3) - cx0 + 1u, cn = cnx * ((ty1 >> 3) - cy0 + 1u);
         for (uint32_t i = lane; i < cn; i += 64u) cs[(size_t)(cy0 + i / cnx) * ctx + cx0 + i % cnx] = T.frame_id;
@@ -2756,7 +2779,8 @@ int launch_selftest_division(uint32_t seed, uint32_t blocks, uint32_t iters, uns
 int launch_classify(const TileParams& t, void* stream)
 {
     // at least one block: block 0 also zeroes the work queue header
-    hipLaunchKernelGGL(classify_tiles, dim3(t.n_cubes ? t.n_cubes : 1u, 1u, 1u), dim3(64u, 1u, 1u), 0, (hipStream_t)stream, t);
+    const uint32_t objects = t.n_cubes + t.n_spheres;
+    hipLaunchKernelGGL(classify_tiles, dim3(objects ? objects : 1u, 1u, 1u), dim3(64u, 1u, 1u), 0, (hipStream_t)stream, t);
     return (int)hipGetLastError();
 }
 

@@ -1067,6 +1067,59 @@ def test_degenerate_spheres(gpu_ctx, oracle_mod, default_scene):
         assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
 
 
+def test_sphere_classification(gpu_ctx, oracle_mod, default_scene):
+    """classify_tiles projects the spheres as well (the bounding box of the sphere grown as in the wave-level sphere cull):
+    a tile that no sphere and no cube projects into is only painted, a tile without spheres skips the sphere pass
+    (src/render.rs:248-276 would cast its rays and find nothing).  Spheres small and large, sub-pixel, across the frame's
+    edges, half outside, with cubes in front of and behind them (and, in a second scene, one sphere behind the eye's plane
+    and a far one that grows the small spheres' boxes past the eye: nothing can be concluded, all is traced); whole frames, bands that do
+    not start on a tile row, the parts of a 3-way split, against the oracle with the ray counters (the skipped pass still
+    counts the reference's list walk).  The counting variant shows that the classification took effect."""
+    import torch
+    s = default_scene
+    m = list(s.materials)
+    V = rt.Vec3
+    spheres = [rt.Sphere(100, V(-6.0, 3.0, -2.0), 1.0, 0), rt.Sphere(101, V(5.5, -2.5, 1.0), 0.6, 1 % len(m)),
+               rt.Sphere(102, V(0.5, 4.2, 2.0), 0.004, 2 % len(m)), rt.Sphere(103, V(13.0, 0.0, -4.0), 2.5, 3 % len(m)),
+               rt.Sphere(104, V(-2.0, -9.5, -6.0), 2.0, 4 % len(m)), rt.Sphere(105, V(-9.0, 6.0, -13.0), 2.0, 5 % len(m)),
+               rt.Sphere(106, V(2.0, 1.0, -14.0), 1.5, 8 % len(m)), rt.Sphere(107, V(1.0, -1.0, 6.5), 0.25, 2 % len(m))]
+    cubes = [rt.Cube(7, V(2.0, 1.0, -8.0), 2.0, 0), rt.Cube(8, V(-6.0, 3.0, -6.0), 3.0, 6 % len(m)), rt.Cube(9, V(6.0, 5.0, 0.0), 1.0, 5 % len(m))]
+    sc = rt.make_scene(cubes, spheres, m, list(s.lights), _cam((0.0, 0.0, 10.0), (0.0, 0.0, 0.0)), s.ambient_light, s.sky_0rgb, s.atlas)
+    for w, h in [(320, 200), (131, 77)]:
+        f, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc, w, h)
+        assert_parity(gfb, gpl, ofb, opl, f"sphere classification {w}x{h}")
+        assert gpu_ctx.count_rays(f).uniq_dict() == ocnt.uniq_dict()
+        assert (gpl["hit_sphere"] != rt.RT_NO_HIT).mean() > 0.01
+    W, H = 320, 200
+    f = sc.frame(W, H)
+    full = gpu_ctx.render(f)
+    _, ex = gpu_ctx.count_executed(f)
+    assert 0 < ex.primary_rays < 0.5 * W * H, ex.primary_rays  # most tiles are sky: painted, no ray generated
+    for y0, y1 in ((0, 61), (3, 150), (93, 200), (150, 151)):
+        assert np.array_equal(gpu_ctx.render(sc.frame(W, H, y0=y0, y1=y1)), full[y0:y1]), (y0, y1)
+    for n in (3,):
+        for p_ in range(n):
+            part = torch.zeros((rt.part_rows(H, n, p_), W), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            gpu_ctx.render_device(f, part.data_ptr(), n_parts=n, part=p_)
+            gpu_ctx.sync()
+            assert np.array_equal(part.cpu().numpy().view(np.uint32), full[rt.part_row_indices(H, n, p_)]), (n, p_)
+    sc2 = rt.make_scene(cubes, spheres + [rt.Sphere(108, V(0.0, 1.0, 14.0), 1.0, 0), rt.Sphere(109, V(-40.0, 25.0, -90.0), 9.0, 1 % len(m))], m,
+                        list(s.lights), sc.camera, s.ambient_light, s.sky_0rgb, s.atlas)
+    f2, gfb, gpl, ofb, opl, ocnt = _both(gpu_ctx, oracle_mod, sc2, 200, 120)
+    assert_parity(gfb, gpl, ofb, opl, "spheres that cannot be projected")
+    assert gpu_ctx.count_rays(f2).uniq_dict() == ocnt.uniq_dict()
+    gpu_ctx.upload(sc)
+    # a camera that turns: stamps of earlier frames must not leak into later ones (frame ids), with and without spheres in view
+    cam = sc.camera
+    for k in range(6):
+        cam = rt.rotate_cam(cam, 1.1, 0.05)
+        fk = sc.frame(160, 96, camera=cam)
+        gk, _ = gpu_ctx.render(fk, debug=True)
+        ok, _, _, _ = oracle_mod.OracleScene(sc).render(fk, debug=True, reuse_secondary=True)
+        assert np.array_equal(gk, ok) and np.array_equal(gpu_ctx.render(fk), ok), k
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_random_scenes(gpu_ctx, oracle_mod, default_scene, seed):
     """Fuzz (parity.random_scene); tests/fuzz_soak.py runs the same generator over hundreds of seeds."""
