@@ -467,7 +467,10 @@ int prepare(rt_ctx* ctx, Params& p, TileScratch& ts, bool heavy_on = false, uint
     t.cube_filt = p.cube_filt;
     t.n_cubes = p.n_cubes;
     // spheres are classified when the cull can bound them (Params::sphere_ok); otherwise their pass is traced everywhere
-    const bool classify_spheres = p.n_spheres != 0u && p.sphere_ok != 0u && std::isfinite(p.sphere_bound_max) && std::isfinite(p.sphere_grow);
+    // (origin_bound is capped at 2^20: an eye beyond that is outside the bound sphere_grow was derived for - the kernels then
+    // keep every sphere, ray_wild - so nothing is concluded here either)
+    const bool classify_spheres = p.n_spheres != 0u && p.sphere_ok != 0u && std::isfinite(p.sphere_bound_max) && std::isfinite(p.sphere_grow) &&
+                                  p.origin_bound < 0x1p20f;
     t.sphere_filt = p.sphere_filt;
     t.n_spheres = classify_spheres ? p.n_spheres : 0u;
     t.sphere_grow = (double)p.sphere_grow;

@@ -1118,6 +1118,12 @@ def test_sphere_classification(gpu_ctx, oracle_mod, default_scene):
         gk, _ = gpu_ctx.render(fk, debug=True)
         ok, _, _, _ = oracle_mod.OracleScene(sc).render(fk, debug=True, reuse_secondary=True)
         assert np.array_equal(gk, ok) and np.array_equal(gpu_ctx.render(fk), ok), k
+    # an eye beyond the bound the spheres' growth was derived for (2^20): no sphere is classified, the frame is the oracle's
+    for eye in ((0.0, 0.0, 3.0e6), (40.0, 5.0, 60.0)):
+        fk = sc.frame(96, 64, camera=_cam(eye, (0.0, 0.0, 0.0)))
+        gk, _ = gpu_ctx.render(fk, debug=True)
+        ok, _, _, _ = oracle_mod.OracleScene(sc).render(fk, debug=True, reuse_secondary=True)
+        assert np.array_equal(gk, ok) and np.array_equal(gpu_ctx.render(fk), ok), eye
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
