@@ -72,8 +72,8 @@ struct WfScratch {
 };
 
 // ---- the allocation-free entry point's work buffers (rt_render_device_noalloc) -------------------------
-// One array per GPU, held until the process ends: queue (64 + 9 x tiles words), stamps (64 + tiles + coarse
-// words) and tile costs (tiles + 1 words) for frames of up to RT_NOALLOC_MAX_TILES 8x8 tiles (6.4 MB).
+// One array per GPU, held until the process ends: queue (64 + 9 x tiles words), stamps (64 + 2 x (tiles + coarse)
+// words: a plane for the cubes, one for the spheres) and tile costs (tiles + 1 words) for frames of up to RT_NOALLOC_MAX_TILES 8x8 tiles (6.4 MB).
 constexpr size_t kNaTiles = RT_NOALLOC_MAX_TILES;
 constexpr size_t kNaQueueWords = kQueueBase + (kCostClasses + 1) * kNaTiles;
 constexpr size_t kNaStampWords = kStampBase + 2 * (kNaTiles + kNaTiles / 16 + 64);  // two planes (cubes, spheres); coarse level: <= tiles/64 + (tiles_x + tiles_y)/8 + 1
